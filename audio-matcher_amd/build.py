@@ -1,0 +1,67 @@
+"""Builds libaudiomatch_amd.so (HIP, gfx950 only) in-tree with hipcc.
+
+Used by __graft_entry__.build(), tests/conftest.py and bench.py.  hipcc
+cross-compiles without a GPU; the resulting .so is git-ignored but travels to
+the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libaudiomatch_amd.so")
+SOURCES = ["am_fft.hip", "am_peaks.hip", "am_api.hip"]
+HEADERS = [os.path.join(CSRC, "am_kernels.h"),
+           os.path.join(HERE, "..", "include", "audiomatch.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and not _stale(LIB, srcs + HEADERS + [os.path.abspath(__file__)]):
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        if force or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

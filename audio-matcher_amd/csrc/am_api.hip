@@ -1,0 +1,765 @@
+// am_api.hip -- host side of libaudiomatch_amd.so: device contexts, transform
+// plans, the needle handle, the overlap-save engine, the chunk driver and the C
+// ABI of include/audiomatch.h.
+//
+// Host-side mirror of the reference's driver (paths relative to the reference):
+//   calc_chunks            src/matcher/audio_matcher.rs:88-141
+//   is_overshadowed        src/matcher/audio_matcher.rs:143-160
+//   start_as_duration      src/matcher/mod.rs:127-129
+//   Mode crop / centered   src/matcher/audio_matcher.rs:450-464
+// All arithmetic on samples runs in the HIP kernels of am_fft.hip /
+// am_peaks.hip; there is no CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "am_kernels.h"
+
+namespace am {
+
+// ---------------------------------------------------------------------------
+static thread_local std::string t_err;
+
+static int fail(int code, const std::string& msg) {
+    t_err = msg;
+    return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    t_err = buf;
+    return e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP;
+}
+#define AM_HIP(call)                                         \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);    \
+    } while (0)
+
+// tuning knobs
+static long long g_opt_log_n = 0;          // 0 = auto
+static long long g_opt_pairs_per_group = 4;
+static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
+static const int kLogNMin = 10, kLogNMax = 23;
+
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return AM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+            if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc(scratch)"); }
+        }
+        cap = want;
+        return AM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return AM_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipHostMalloc"); }
+        cap = bytes;
+        return AM_OK;
+    }
+};
+
+struct Plan {
+    PlanDev dev{};
+    float2* tables = nullptr;  // one allocation holding the four tables
+};
+
+struct ProfRec { int name; hipEvent_t e0, e1; };
+static const char* kKernelNames[] = {"k1_cols_fwd", "k2_rows", "k3_cols_inv", "tile_stats", "peaks", "other"};
+enum { KN_K1 = 0, KN_K2, KN_K3, KN_STATS, KN_PEAKS, KN_OTHER, KN_COUNT };
+
+struct Ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::recursive_mutex mu;
+    std::map<int, Plan> plans;
+    DevBuf work, scores, stats, segs, peaks, counts, io_in, io_out, sum;
+    HostBuf pinned;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> pool;
+    double prof_ms[KN_COUNT] = {0};
+    uint64_t prof_n[KN_COUNT] = {0};
+};
+
+static std::mutex g_ctx_mu;
+static std::map<int, Ctx*> g_ctx;
+static bool g_kernels_ready = false;
+
+static int get_ctx(int device, Ctx** out) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(AM_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(AM_ERR_NO_DEVICE, "device ordinal out of range");
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) { *out = it->second; AM_HIP(hipSetDevice(device)); return AM_OK; }
+    AM_HIP(hipSetDevice(device));
+    if (!g_kernels_ready) {
+        AM_HIP(fft_kernels_init());
+        g_kernels_ready = true;
+    }
+    Ctx* c = new Ctx();
+    c->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
+    g_ctx[device] = c;
+    *out = c;
+    return AM_OK;
+}
+
+// ---- profiling helpers ------------------------------------------------------
+static hipEvent_t prof_event(Ctx* c) {
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    Ctx* c; int name; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(Ctx* c_, int name_) : c(c_), name(name_) {
+        if (c->prof) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, c->stream); }
+    }
+    ~ProfScope() {
+        if (c->prof) { (void)hipEventRecord(e1, c->stream); c->pending.push_back({name, e0, e1}); }
+    }
+};
+static void prof_harvest(Ctx* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { c->prof_ms[r.name] += ms; c->prof_n[r.name] += 1; }
+        c->pool.push_back(r.e0); c->pool.push_back(r.e1);
+    }
+    c->pending.clear();
+}
+
+// ---- plans --------------------------------------------------------------------
+static void fill_twiddles(std::vector<float2>& v, size_t off, size_t count, double denom, double mult) {
+    for (size_t k = 0; k < count; ++k) {
+        const double ang = -2.0 * M_PI * (double)k * mult / denom;
+        v[off + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+}
+
+static int get_plan(Ctx* c, int logN, const Plan** out) {
+    auto it = c->plans.find(logN);
+    if (it != c->plans.end()) { *out = &it->second; return AM_OK; }
+    if (logN < kLogNMin || logN > kLogNMax) return fail(AM_ERR_INVALID_ARG, "unsupported transform size");
+    Plan p;
+    int logN1 = logN - 13;
+    if (logN1 < kColsLog) logN1 = kColsLog;
+    if (logN1 > 9) logN1 = 9;
+    const int logN2 = logN - logN1;
+    const int logLo = (logN + 1) / 2;
+    const size_t n1h = (size_t)1 << (logN1 - 1), n2h = (size_t)1 << (logN2 - 1);
+    const size_t nlo = (size_t)1 << logLo, nhi = (size_t)1 << (logN - logLo);
+    std::vector<float2> host(n1h + n2h + nlo + nhi);
+    fill_twiddles(host, 0, n1h, (double)(1u << logN1), 1.0);
+    fill_twiddles(host, n1h, n2h, (double)(1u << logN2), 1.0);
+    fill_twiddles(host, n1h + n2h, nlo, (double)((size_t)1 << logN), 1.0);
+    fill_twiddles(host, n1h + n2h + nlo, nhi, (double)((size_t)1 << logN), (double)nlo);
+    AM_HIP(hipMalloc((void**)&p.tables, host.size() * sizeof(float2)));
+    AM_HIP(hipMemcpy(p.tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
+    p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo;
+    p.dev.tw1 = p.tables;
+    p.dev.tw2 = p.tables + n1h;
+    p.dev.twlo = p.tables + n1h + n2h;
+    p.dev.twhi = p.tables + n1h + n2h + nlo;
+    auto ins = c->plans.emplace(logN, p);
+    *out = &ins.first->second;
+    return AM_OK;
+}
+
+}  // namespace am
+
+// ---------------------------------------------------------------------------
+struct am_needle {
+    am::Ctx* ctx = nullptr;
+    float* d_needle = nullptr;
+    size_t n = 0;
+    float inv_autocorr = 0.f;
+    std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
+};
+
+namespace am {
+
+static int pick_log_n(size_t s, long long out_count, int* logN_out) {
+    // smallest transform that can hold the needle at all
+    int min_log = kLogNMin;
+    while (min_log <= kLogNMax && ((size_t)1 << min_log) < s + 1) ++min_log;
+    if (min_log > kLogNMax) return fail(AM_ERR_INVALID_ARG, "needle too long for the largest transform (2^23)");
+    if (g_opt_log_n > 0) {
+        int l = (int)g_opt_log_n;
+        if (l < min_log) l = min_log;
+        if (l > kLogNMax) l = kLogNMax;
+        *logN_out = l;
+        return AM_OK;
+    }
+    int pref = min_log;
+    while (pref < kLogNMax) {
+        const double n = (double)((size_t)1 << pref);
+        if ((n - (double)s + 1.0) / n >= kMinEfficiency) break;
+        ++pref;
+    }
+    // whole problem in one block if that is smaller
+    const long long span = out_count + (long long)s - 1;
+    int single = kLogNMin;
+    while (single < kLogNMax && (long long)((size_t)1 << single) < span) ++single;
+    *logN_out = std::min(pref, std::max(single, min_log));
+    return AM_OK;
+}
+
+static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
+    Ctx* c = h->ctx;
+    auto it = h->spectra.find(pl->dev.logN);
+    if (it != h->spectra.end()) { *out = it->second; return AM_OK; }
+    const size_t N = (size_t)1 << pl->dev.logN;
+    int rc = c->work.ensure(std::max<size_t>(N * sizeof(float2), c->work.cap));
+    if (rc) return rc;
+    float2* hc = nullptr;
+    AM_HIP(hipMalloc((void**)&hc, N * sizeof(float2)));
+    Job job{};
+    job.src = h->d_needle; job.src_len = (long long)h->n; job.lead = 0;
+    job.dst = nullptr; job.out_count = 0; job.hop = 1; job.nblocks = 1; job.first_pair = 0;
+    {
+        ProfScope ps(c, KN_OTHER);
+        AM_HIP(launch_k1(c->stream, job, 1, (float2*)c->work.p, pl->dev));
+        AM_HIP(launch_k2_spectrum(c->stream, (float2*)c->work.p, hc, pl->dev));
+    }
+    AM_HIP(hipStreamSynchronize(c->stream));
+    h->spectra[pl->dev.logN] = hc;
+    *out = hc;
+    return AM_OK;
+}
+
+// The overlap-save engine: scores[j] = factor * sum_n X[j + n - lead] needle[n]
+static int run_correlation(am_needle* h, const float* d_src, long long src_len, long long lead,
+                           float* d_dst, long long out_count, float factor) {
+    Ctx* c = h->ctx;
+    int logN = 0;
+    int rc = pick_log_n(h->n, out_count, &logN);
+    if (rc) return rc;
+    const Plan* pl = nullptr;
+    if ((rc = get_plan(c, logN, &pl))) return rc;
+    const float2* hc = nullptr;
+    if ((rc = needle_spectrum(h, pl, &hc))) return rc;
+    const long long N = 1ll << logN;
+    long long hop = N - (long long)h->n + 1;
+    if (hop >= 8 * kTile) hop = (hop / kTile) * kTile;
+    const long long nblocks = (out_count + hop - 1) / hop;
+    const long long npairs = (nblocks + 1) / 2;
+    long long ppg = std::max<long long>(1, g_opt_pairs_per_group);
+    if (ppg > npairs) ppg = npairs;
+    if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
+    Job job{};
+    job.src = d_src; job.src_len = src_len; job.lead = lead;
+    job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
+    for (long long first = 0; first < npairs; first += ppg) {
+        const int np = (int)std::min(ppg, npairs - first);
+        job.first_pair = (int)first;
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev)); }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, factor)); }
+    }
+    return AM_OK;
+}
+
+static float scale_factor(const am_needle* h, int scale, size_t w) {
+    if (scale == AM_SCALE_LIB) return h->inv_autocorr;                 // audio_matcher.rs:306-308
+    if (scale == AM_SCALE_MY) return h->inv_autocorr / (float)w;       // audio_matcher.rs:444-447
+    return 1.0f;
+}
+
+static size_t mode_len(size_t w, size_t s, int mode) {                // audio_matcher.rs:450-456
+    if (mode == AM_MODE_FULL) return w + s - 1;
+    if (mode == AM_MODE_SAME) return w;
+    return (w > s ? w - s : 0) + 1;
+}
+
+// Duration::from_secs_f64(start as f64 / sr as f64) in whole nanoseconds
+// (matcher/mod.rs:127-129); exact on the f64 bits, round-to-nearest-even.
+static uint64_t start_nanos(uint64_t start, uint32_t sr) {
+    const double t = (double)start / (double)sr;
+    if (!(t > 0.0)) return 0;
+    int e = 0;
+    const double m = std::frexp(t, &e);
+    const unsigned long long mant = (unsigned long long)std::ldexp(m, 53);
+    const int sh = e - 53;
+    unsigned __int128 v = (unsigned __int128)mant * 1000000000ull;
+    if (sh >= 0) return (uint64_t)(v << sh);
+    const int r = -sh;
+    if (r >= 127) return 0;
+    unsigned __int128 q = v >> r;
+    const unsigned __int128 rem = v & (((unsigned __int128)1 << r) - 1);
+    const unsigned __int128 half = (unsigned __int128)1 << (r - 1);
+    if (rem > half || (rem == half && (q & 1))) ++q;
+    return (uint64_t)q;
+}
+
+// audio_matcher.rs:143-160
+static bool is_overshadowed(const am_peak& element, const am_peak* other, uint32_t sr, double max_distance_s) {
+    if (!other) return false;
+    uint64_t e = start_nanos(element.start, sr), b = start_nanos(other->start, sr);
+    if (e < b) std::swap(e, b);
+    const uint64_t maxd = (uint64_t)std::llround(max_distance_s * 1e9);
+    return (e - b) < maxd && other->prominence > element.prominence;
+}
+
+// find_peaks (audio_matcher.rs:221-230) on every segment of a resident score
+// array; results are appended segment by segment, each by descending height.
+static int pick_peaks(Ctx* c, const float* d_scores, long long n_scores, const std::vector<Segment>& segs,
+                      float min_prom, long long min_dist, std::vector<am_peak>& all) {
+    const int nsegs = (int)segs.size();
+    if (nsegs == 0 || n_scores <= 0) return AM_OK;
+    int rc;
+    const long long ntiles = (n_scores + kTile - 1) / kTile;
+    if ((rc = c->stats.ensure((size_t)ntiles * sizeof(float2)))) return rc;
+    { ProfScope ps(c, KN_STATS); AM_HIP(launch_tile_stats(c->stream, d_scores, n_scores, (float2*)c->stats.p)); }
+    const size_t seg_bytes = sizeof(Segment) * nsegs;
+    const size_t cnt_bytes = sizeof(int) * (nsegs + 1);
+    if ((rc = c->segs.ensure(seg_bytes))) return rc;
+    if ((rc = c->counts.ensure(cnt_bytes))) return rc;
+    if ((rc = c->peaks.ensure(sizeof(am_peak) * (size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    if ((rc = c->pinned.ensure(std::max(seg_bytes, cnt_bytes) + 64))) return rc;
+    memcpy(c->pinned.p, segs.data(), seg_bytes);
+    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, seg_bytes, hipMemcpyHostToDevice, c->stream));
+    AM_HIP(hipMemsetAsync(c->counts.p, 0, cnt_bytes, c->stream));
+    int* d_counts = (int*)c->counts.p;
+    int* d_err = d_counts + nsegs;
+    {
+        ProfScope ps(c, KN_PEAKS);
+        AM_HIP(launch_peaks(c->stream, d_scores, n_scores, (const float2*)c->stats.p,
+                            (const Segment*)c->segs.p, nsegs, min_prom, min_dist,
+                            (am_peak*)c->peaks.p, d_counts, d_err));
+    }
+    AM_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int> counts(nsegs + 1);
+    AM_HIP(hipMemcpy(counts.data(), d_counts, cnt_bytes, hipMemcpyDeviceToHost));
+    if (counts[nsegs]) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+    for (int i = 0; i < nsegs; ++i) {
+        if (counts[i] <= 0) continue;
+        const size_t old = all.size();
+        all.resize(old + counts[i]);
+        AM_HIP(hipMemcpy(all.data() + old, (am_peak*)c->peaks.p + (size_t)i * AM_MAX_PEAKS_PER_CHUNK,
+                         sizeof(am_peak) * counts[i], hipMemcpyDeviceToHost));
+    }
+    return AM_OK;
+}
+
+// calc_chunks on a resident haystack (audio_matcher.rs:88-141)
+static int match_device(am_needle* h, const float* d_hay, size_t len, const am_match_params* p,
+                        am_peak* out, size_t cap, size_t* n_out) {
+    Ctx* c = h->ctx;
+    const size_t s = h->n;
+    *n_out = 0;
+    if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
+    if (len < s) return AM_OK;  // no window holds a complete needle
+    const long long out_count = (long long)(len - s + 1);
+    int rc;
+    if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
+    if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
+        return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB (AM_SCALE_MY depends on the window length)");
+    const float factor = scale_factor(h, p->scale, 1);
+    if ((rc = run_correlation(h, d_hay, (long long)len, 0, (float*)c->scores.p, out_count, factor))) return rc;
+    // windows: common::chunked(chunk + overlap, hop = chunk) (audio_matcher.rs:104)
+    std::vector<Segment> segs;
+    const unsigned long long window = p->chunk + p->overlap;
+    for (unsigned long long off = 0; off < len; off += p->chunk) {
+        const unsigned long long w = std::min<unsigned long long>(window, len - off);
+        if (w < s) continue;
+        Segment sg; sg.a = (long long)off; sg.b = (long long)(off + w - s + 1);
+        segs.push_back(sg);
+    }
+    // per-chunk find_peaks, collected in window order (audio_matcher.rs:124-133)
+    std::vector<am_peak> all;
+    if ((rc = pick_peaks(c, (const float*)c->scores.p, out_count, segs, p->min_prominence,
+                         (long long)p->min_distance, all))) return rc;
+    // sorted_by position.start, stable (audio_matcher.rs:135)
+    std::stable_sort(all.begin(), all.end(), [](const am_peak& x, const am_peak& y) { return x.start < y.start; });
+    // filter_surrounding (audio_matcher.rs:136-139): neighbours of the sorted, unfiltered sequence
+    size_t n = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+        const am_peak* before = i > 0 ? &all[i - 1] : nullptr;
+        const am_peak* after = i + 1 < all.size() ? &all[i + 1] : nullptr;
+        if (is_overshadowed(all[i], before, p->sr, p->overshadow_distance_s) ||
+            is_overshadowed(all[i], after, p->sr, p->overshadow_distance_s))
+            continue;
+        if (n < cap) out[n] = all[i];
+        ++n;
+    }
+    *n_out = n;
+    if (n > cap) return fail(AM_ERR_CAPACITY, "peak output buffer too small");
+    return AM_OK;
+}
+
+static int check_needle(const am_needle* h) {
+    if (!h || !h->ctx) return fail(AM_ERR_INVALID_ARG, "null needle handle");
+    AM_HIP(hipSetDevice(h->ctx->device));
+    return AM_OK;
+}
+
+static int create_needle_common(Ctx* c, float* d_needle, size_t n, am_needle** out) {
+    am_needle* h = new am_needle();
+    h->ctx = c; h->d_needle = d_needle; h->n = n;
+    int rc = c->sum.ensure(sizeof(double));
+    if (rc) { (void)hipFree(d_needle); delete h; return rc; }
+    hipError_t e = launch_sumsq(c->stream, d_needle, (long long)n, (double*)c->sum.p);
+    double ss = 0.0;
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(&ss, c->sum.p, sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { (void)hipFree(d_needle); delete h; return hip_fail(e, "needle energy"); }
+    h->inv_autocorr = (float)(1.0 / ss);   // audio_matcher.rs:321-329
+    *out = h;
+    return AM_OK;
+}
+
+}  // namespace am
+
+using namespace am;
+
+// ===========================================================================
+extern "C" {
+
+int am_abi_version(void) { return AM_ABI_VERSION; }
+const char* am_last_error_string(void) { return t_err.c_str(); }
+
+int am_device_count(int* n) {
+    if (!n) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) { *n = 0; return fail(AM_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *n = k;
+    return AM_OK;
+}
+
+int am_needle_create(int device, const float* needle, size_t n, am_needle** out) {
+    if (!needle || !out || n == 0) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    float* d = nullptr;
+    AM_HIP(hipMalloc((void**)&d, n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, needle, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(needle)"); }
+    return create_needle_common(c, d, n, out);
+}
+
+int am_needle_create_device(int device, const float* d_needle, size_t n, am_needle** out) {
+    if (!d_needle || !out || n == 0) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    float* d = nullptr;
+    AM_HIP(hipMalloc((void**)&d, n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, d_needle, n * sizeof(float), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(needle d2d)"); }
+    return create_needle_common(c, d, n, out);
+}
+
+void am_needle_destroy(am_needle* h) {
+    if (!h) return;
+    if (h->ctx) {
+        std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+        (void)hipSetDevice(h->ctx->device);
+        (void)hipStreamSynchronize(h->ctx->stream);
+        for (auto& kv : h->spectra) (void)hipFree(kv.second);
+        if (h->d_needle) (void)hipFree(h->d_needle);
+    }
+    delete h;
+}
+
+int am_needle_len(const am_needle* h, size_t* n) {
+    if (!h || !n) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    *n = h->n;
+    return AM_OK;
+}
+
+int am_needle_inv_autocorr(const am_needle* h, float* out) {
+    if (!h || !out) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    *out = h->inv_autocorr;
+    return AM_OK;
+}
+
+int am_correlate_len(size_t w, size_t s, int mode, size_t* out_len) {
+    if (!out_len || w == 0 || s == 0 || mode < 0 || mode > 2) return fail(AM_ERR_INVALID_ARG, "bad argument");
+    *out_len = mode_len(w, s, mode);
+    return AM_OK;
+}
+
+static int correlate_impl(const am_needle* hc, const float* within, size_t w, int mode, int scale,
+                          float* out, size_t cap, size_t* out_len, bool device_io) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!within || !out_len || w == 0) return fail(AM_ERR_INVALID_ARG, "within must be non-empty");
+    if (mode < AM_MODE_FULL || mode > AM_MODE_VALID) return fail(AM_ERR_INVALID_ARG, "bad mode");
+    if (scale < AM_SCALE_NONE || scale > AM_SCALE_MY) return fail(AM_ERR_INVALID_ARG, "bad scale");
+    const size_t s = h->n;
+    const size_t len = mode_len(w, s, mode);
+    *out_len = len;
+    if (cap < len || !out) return fail(AM_ERR_CAPACITY, "output buffer too small");
+    // centered(): start = (full - len) / 2 (audio_matcher.rs:460-464)
+    const size_t start = (w + s - 1 - len) / 2;
+    const long long lead = (long long)(s - 1) - (long long)start;
+    Ctx* c = h->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const float* d_in = within;
+    float* d_out = out;
+    if (!device_io) {
+        if ((rc = c->io_in.ensure(w * sizeof(float)))) return rc;
+        if ((rc = c->io_out.ensure(len * sizeof(float)))) return rc;
+        AM_HIP(hipMemcpy(c->io_in.p, within, w * sizeof(float), hipMemcpyHostToDevice));
+        d_in = (const float*)c->io_in.p;
+        d_out = (float*)c->io_out.p;
+    }
+    if ((rc = run_correlation(h, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
+    AM_HIP(hipStreamSynchronize(c->stream));
+    if (!device_io) AM_HIP(hipMemcpy(out, d_out, len * sizeof(float), hipMemcpyDeviceToHost));
+    return AM_OK;
+}
+
+int am_correlate(const am_needle* h, const float* within, size_t w, int mode, int scale,
+                 float* out, size_t cap, size_t* out_len) {
+    return correlate_impl(h, within, w, mode, scale, out, cap, out_len, false);
+}
+
+int am_correlate_device(const am_needle* h, const float* d_within, size_t w, int mode, int scale,
+                        float* d_out, size_t cap, size_t* out_len) {
+    return correlate_impl(h, d_within, w, mode, scale, d_out, cap, out_len, true);
+}
+
+int am_match_device(const am_needle* hc, const float* d_haystack, size_t len,
+                    const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!d_haystack || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (len == 0) { *n_out = 0; return AM_OK; }
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    return match_device(h, d_haystack, len, p, out, cap, n_out);
+}
+
+int am_match(const am_needle* hc, const float* haystack, size_t len,
+             const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!haystack || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (len == 0) { *n_out = 0; return AM_OK; }
+    Ctx* c = h->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if ((rc = c->io_in.ensure(len * sizeof(float)))) return rc;
+    AM_HIP(hipMemcpy(c->io_in.p, haystack, len * sizeof(float), hipMemcpyHostToDevice));
+    return match_device(h, (const float*)c->io_in.p, len, p, out, cap, n_out);
+}
+
+int am_match_batch_device(const am_needle* hc, const float* const* d_haystacks, const size_t* lens,
+                          size_t n_hay, const am_match_params* p,
+                          am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!d_haystacks || !lens || !p || !n_out || (!out && cap_per_hay)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    int worst = AM_OK;
+    for (size_t k = 0; k < n_hay; ++k) {
+        n_out[k] = 0;
+        if (!d_haystacks[k] || lens[k] == 0) continue;
+        rc = match_device(h, d_haystacks[k], lens[k], p, out + k * cap_per_hay, cap_per_hay, &n_out[k]);
+        if (rc == AM_ERR_CAPACITY) { worst = rc; continue; }
+        if (rc) return rc;
+    }
+    return worst;
+}
+
+int am_find_peaks(int device, const float* scores, size_t n, float min_prominence,
+                  uint64_t min_distance, am_peak* out, size_t cap, size_t* n_out) {
+    if (!scores || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    *n_out = 0;
+    if (n == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if ((rc = c->io_in.ensure(n * sizeof(float)))) return rc;
+    AM_HIP(hipMemcpy(c->io_in.p, scores, n * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<Segment> segs(1);
+    segs[0].a = 0; segs[0].b = (long long)n;
+    std::vector<am_peak> all;
+    if ((rc = pick_peaks(c, (const float*)c->io_in.p, (long long)n, segs, min_prominence,
+                         (long long)min_distance, all))) return rc;
+    *n_out = all.size();
+    for (size_t i = 0; i < all.size() && i < cap; ++i) out[i] = all[i];
+    if (all.size() > cap) return fail(AM_ERR_CAPACITY, "peak output buffer too small");
+    return AM_OK;
+}
+
+int am_pcm_s16_stereo_to_mono_device(int device, const int16_t* d_in, size_t frames, float* d_out) {
+    if (!d_in || !d_out) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (frames == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    AM_HIP(launch_pcm_downmix(c->stream, d_in, (long long)frames, d_out));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_pcm_s16_stereo_to_mono(int device, const int16_t* interleaved, size_t frames, float* out) {
+    if (!interleaved || !out) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (frames == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if ((rc = c->io_in.ensure(frames * 2 * sizeof(int16_t)))) return rc;
+    if ((rc = c->io_out.ensure(frames * sizeof(float)))) return rc;
+    AM_HIP(hipMemcpy(c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    AM_HIP(launch_pcm_downmix(c->stream, (const int16_t*)c->io_in.p, (long long)frames, (float*)c->io_out.p));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    AM_HIP(hipMemcpy(out, c->io_out.p, frames * sizeof(float), hipMemcpyDeviceToHost));
+    return AM_OK;
+}
+
+int am_device_malloc(int device, size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(AM_ERR_INVALID_ARG, "bad argument");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    AM_HIP(hipMalloc(out, bytes));
+    return AM_OK;
+}
+int am_device_free(int device, void* p) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (p) AM_HIP(hipFree(p));
+    return AM_OK;
+}
+int am_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    AM_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return AM_OK;
+}
+int am_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    AM_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return AM_OK;
+}
+int am_device_synchronize(int device) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    AM_HIP(hipDeviceSynchronize());
+    return AM_OK;
+}
+
+int am_synth_uniform_device(int device, float* d_out, uint32_t seed, uint32_t stream,
+                            uint64_t first, size_t n, float amp) {
+    if (!d_out) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (n == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    AM_HIP(launch_synth(c->stream, d_out, seed, stream, first, (long long)n, amp));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float gain) {
+    if (!d_dst || !d_src) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (n == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    AM_HIP(launch_axpy(c->stream, d_dst, d_src, (long long)n, gain));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_profile_enable(int device, int on) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    prof_harvest(c);
+    c->prof = on != 0;
+    return AM_OK;
+}
+int am_profile_reset(int device) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    prof_harvest(c);
+    for (int i = 0; i < KN_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return AM_OK;
+}
+int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t* launches) {
+    if (!kernel || !total_ms || !launches) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    prof_harvest(c);
+    double ms = 0; uint64_t n = 0; bool found = false;
+    for (int i = 0; i < KN_COUNT; ++i) {
+        if (!strcmp(kernel, "*") || !strcmp(kernel, kKernelNames[i])) { ms += c->prof_ms[i]; n += c->prof_n[i]; found = true; }
+    }
+    if (!found) return fail(AM_ERR_INVALID_ARG, "unknown kernel name");
+    *total_ms = ms; *launches = n;
+    return AM_OK;
+}
+
+int am_set_option(const char* key, long long value) {
+    if (!key) return fail(AM_ERR_INVALID_ARG, "null key");
+    if (!strcmp(key, "log_n")) {
+        if (value != 0 && (value < kLogNMin || value > kLogNMax)) return fail(AM_ERR_INVALID_ARG, "log_n out of range");
+        g_opt_log_n = value; return AM_OK;
+    }
+    if (!strcmp(key, "pairs_per_group")) {
+        if (value < 1 || value > 64) return fail(AM_ERR_INVALID_ARG, "pairs_per_group out of range");
+        g_opt_pairs_per_group = value; return AM_OK;
+    }
+    return fail(AM_ERR_INVALID_ARG, "unknown option");
+}
+int am_get_option(const char* key, long long* value) {
+    if (!key || !value) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (!strcmp(key, "log_n")) { *value = g_opt_log_n; return AM_OK; }
+    if (!strcmp(key, "pairs_per_group")) { *value = g_opt_pairs_per_group; return AM_OK; }
+    return fail(AM_ERR_INVALID_ARG, "unknown option");
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// am_kernels.h -- device-side job descriptors and launcher prototypes shared by
+// the HIP translation units of libaudiomatch_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/audiomatch.h"
+
+namespace am {
+
+// One overlap-save job: a (virtually zero-padded) input signal and the score
+// array it produces.  score[j] = sum_n X[j + n - lead] * needle[n], X = 0
+// outside [0, src_len).  Block b reads input [b*hop - lead, b*hop - lead + N)
+// and yields scores [b*hop, b*hop + hop).  Two blocks are packed into one
+// complex transform (re = block 2g, im = block 2g+1).
+struct Job {
+    const float* src;     // device
+    long long src_len;
+    long long lead;       // virtual zeros in front of src[0]
+    float* dst;           // device, out_count scores
+    long long out_count;
+    int hop;              // new scores per block (<= N - S + 1)
+    int nblocks;          // ceil(out_count / hop)
+    int first_pair;       // first pair handled by this launch (slot 0 of work)
+};
+
+// Factorisation N = N1 * N2 of the complex transform and its twiddle tables.
+struct PlanDev {
+    int logN, logN1, logN2, logLo;
+    const float2* tw1;    // W_N1^k, k < N1/2 (forward sign)
+    const float2* tw2;    // W_N2^k, k < N2/2
+    const float2* twlo;   // W_N^m,            m < 2^logLo
+    const float2* twhi;   // W_N^(m << logLo), m < 2^(logN - logLo)
+};
+
+constexpr int kColsLog = 5;            // B = 32 columns per K1/K3 workgroup
+constexpr int kCols = 1 << kColsLog;
+constexpr int kTile = 1024;            // score tile of the min/max summary
+constexpr int kFftThreads = 256;
+
+// one reference chunk's slice of a score array (audio_matcher.rs:119-126)
+struct Segment {
+    long long a, b;       // [a, b) in the score array
+};
+
+hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl);
+hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl);
+hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
+hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
+                     const PlanDev& pl, float out_scale);
+hipError_t fft_kernels_init();
+
+hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats);
+hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
+                        const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
+                        am_peak* d_out, int* d_out_n, int* d_err);
+hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_out);
+hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
+                        long long n, float amp);
+hipError_t launch_axpy(hipStream_t st, float* dst, const float* src, long long n, float gain);
+hipError_t launch_pcm_downmix(hipStream_t st, const int16_t* in, long long frames, float* out);
+
+}  // namespace am

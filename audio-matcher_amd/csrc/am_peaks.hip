@@ -1,0 +1,373 @@
+// am_peaks.hip -- score scan + peak pick kernels of libaudiomatch_amd.so (gfx950).
+//
+// Replaces find_peaks() of the reference (audio_matcher.rs:221-230), i.e.
+// find_peaks::PeakFinder::new(scores).with_min_prominence(p)
+//     .with_min_distance(d).find_peaks(), run per reference chunk on the slice
+// [a, b) of the haystack's global score array (audio_matcher.rs:119-126).
+//
+// Semantics (crate find_peaks 0.1, scipy-style; see oracle/oracle.c for the
+// pinning status of each rule):
+//   local maximum with flat top: x[i-1] < x[i] == ... == x[k-1] > x[k],
+//   never at the first/last sample of the chunk; prominence = height -
+//   max(left_min, right_min), each min taken outwards until a strictly higher
+//   sample or the chunk edge; keep prominence >= min_prominence; then greedy
+//   min_distance filter by descending height; output by descending height.
+//
+// Design: a min/max summary per 1024-score tile lets one workgroup per chunk
+//   (1) get the chunk minimum, (2) skip every tile that cannot hold a
+//   qualifying peak (prominence <= height - chunk_min), (3) walk the
+//   prominence ranges tile-wise; raw scores are only touched in candidate
+//   tiles and at the two ends of each walk.  Walks are wavefront-cooperative:
+//   64 lanes look at 64 samples / 64 tile summaries per step and agree on the
+//   stopping point with a ballot.
+#include "am_kernels.h"
+
+#include <float.h>
+
+namespace am {
+
+constexpr int kPeakThreads = 256;
+constexpr int kWaves = kPeakThreads / 64;
+constexpr int kQueueCap = kTile;  // local maxima of one tile (<= kTile/2, head/tail pieces < kTile)
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, long long n, float2* __restrict__ stats) {
+    __shared__ float smin[4], smax[4];
+    const long long base = (long long)blockIdx.x * kTile;
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    for (int i = threadIdx.x; i < kTile; i += 256) {
+        const long long idx = base + i;
+        if (idx < n) { const float v = g[idx]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { smin[wv] = mn; smax[wv] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { mn = fminf(mn, smin[k]); mx = fmaxf(mx, smax[k]); }
+        stats[blockIdx.x] = make_float2(fminf(mn, smin[0]), fmaxf(mx, smax[0]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+struct Cand { long long ps, pe; float h; };
+
+// One wave-cooperative step of the walk to the left of `cur` (exclusive) down
+// to `a`: either skips up to 64 whole tiles through their summaries or looks at
+// up to 64 raw samples.  Returns true when a strictly higher sample ended the
+// walk; `cur` reaching `a` ends it at the chunk edge.
+__device__ __forceinline__ bool step_left(const float* __restrict__ g, const float2* __restrict__ stats,
+                                          long long a, long long& cur, float h, float& vmin, int lane) {
+    if ((cur % kTile) == 0 && cur - kTile >= a) {
+        const long long t = cur / kTile - 1 - lane;
+        const bool valid = t >= 0 && t * (long long)kTile >= a;
+        float2 st = make_float2(FLT_MAX, -FLT_MAX);
+        if (valid) st = stats[t];
+        const unsigned long long blocked = __ballot(valid && st.y > h);
+        const int nvalid = __popcll(__ballot(valid));
+        const int nskip = blocked ? (__ffsll((long long)blocked) - 1) : nvalid;
+        if (nskip > 0) {
+            vmin = fminf(vmin, wave_min(lane < nskip ? st.x : FLT_MAX));
+            cur -= (long long)nskip * kTile;
+            return false;
+        }
+    }
+    const long long tile_lo = ((cur - 1) / kTile) * kTile;
+    const long long lo = tile_lo > a ? tile_lo : a;
+    const long long idx = cur - 1 - lane;
+    const bool valid = idx >= lo;
+    const float v = valid ? g[idx] : 0.0f;
+    const unsigned long long higher = __ballot(valid && v > h);
+    const int nval = __popcll(__ballot(valid));
+    const int ntake = higher ? (__ffsll((long long)higher) - 1) : nval;
+    vmin = fminf(vmin, wave_min(lane < ntake ? v : FLT_MAX));
+    cur -= ntake;
+    return higher != 0ull;
+}
+
+// Mirror image: walk to the right from `cur` (inclusive) up to `b` (exclusive).
+__device__ __forceinline__ bool step_right(const float* __restrict__ g, const float2* __restrict__ stats,
+                                           long long b, long long& cur, float h, float& vmin, int lane) {
+    if ((cur % kTile) == 0 && cur + kTile <= b) {
+        const long long t = cur / kTile + lane;
+        const bool valid = (t + 1) * (long long)kTile <= b;
+        float2 st = make_float2(FLT_MAX, -FLT_MAX);
+        if (valid) st = stats[t];
+        const unsigned long long blocked = __ballot(valid && st.y > h);
+        const int nvalid = __popcll(__ballot(valid));
+        const int nskip = blocked ? (__ffsll((long long)blocked) - 1) : nvalid;
+        if (nskip > 0) {
+            vmin = fminf(vmin, wave_min(lane < nskip ? st.x : FLT_MAX));
+            cur += (long long)nskip * kTile;
+            return false;
+        }
+    }
+    const long long tile_hi = (cur / kTile + 1) * kTile;
+    const long long hi = tile_hi < b ? tile_hi : b;
+    const long long idx = cur + lane;
+    const bool valid = idx < hi;
+    const float v = valid ? g[idx] : 0.0f;
+    const unsigned long long higher = __ballot(valid && v > h);
+    const int nval = __popcll(__ballot(valid));
+    const int ntake = higher ? (__ffsll((long long)higher) - 1) : nval;
+    vmin = fminf(vmin, wave_min(lane < ntake ? v : FLT_MAX));
+    cur += ntake;
+    return higher != 0ull;
+}
+
+// Prominence of the flat-topped maximum [ps, pe) of height h inside chunk
+// [a, b); both walks advance in lock step so that a side lobe next to a taller
+// peak is rejected after a few samples (prominence <= h - min of a finished
+// side).  Returns false when prominence < min_prom.
+__device__ bool prominence(const float* __restrict__ g, const float2* __restrict__ stats,
+                           long long a, long long b, long long ps, long long pe, float h,
+                           float min_prom, int lane, float& prom) {
+    long long cl = ps, cr = pe;
+    float lmin = h, rmin = h;
+    bool dl = cl <= a, dr = cr >= b;
+    while (!dl || !dr) {
+        if (!dl) {
+            const bool stopped = step_left(g, stats, a, cl, h, lmin, lane);
+            dl = stopped || cl <= a;
+            if (dl && !((h - lmin) >= min_prom)) return false;
+        }
+        if (!dr) {
+            const bool stopped = step_right(g, stats, b, cr, h, rmin, lane);
+            dr = stopped || cr >= b;
+            if (dr && !((h - rmin) >= min_prom)) return false;
+        }
+    }
+    prom = h - fmaxf(lmin, rmin);
+    return prom >= min_prom;
+}
+
+__global__ void __launch_bounds__(kPeakThreads)
+peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
+             const Segment* __restrict__ segs, float min_prom, long long min_dist,
+             am_peak* __restrict__ out, int* __restrict__ out_n, int* __restrict__ err) {
+    __shared__ float red[kWaves];
+    __shared__ float seg_min_s;
+    __shared__ Cand queue[kQueueCap];
+    __shared__ int queue_n;
+    __shared__ am_peak res[AM_MAX_PEAKS_PER_CHUNK];
+    __shared__ int res_n;
+    __shared__ int order[AM_MAX_PEAKS_PER_CHUNK];
+    __shared__ int overflow;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Segment sg = segs[blockIdx.x];
+    const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
+    am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
+    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; }
+    if (b - a < 3) {
+        if (tid == 0) out_n[blockIdx.x] = 0;
+        return;
+    }
+    // full tiles [tf, tl) lie completely inside [a, b)
+    const long long tf = (a + kTile - 1) / kTile;
+    const long long tl = b / kTile;
+    const bool has_full = tl > tf;
+    const long long head_hi = has_full ? tf * kTile : b;   // raw head piece [a, head_hi)
+    const long long tail_lo = has_full ? tl * kTile : b;   // raw tail piece [tail_lo, b)
+
+    // ---- chunk minimum ----------------------------------------------------
+    float mn = FLT_MAX;
+    for (long long i = a + tid; i < head_hi; i += kPeakThreads) mn = fminf(mn, g[i]);
+    for (long long i = tail_lo + tid; i < b; i += kPeakThreads) mn = fminf(mn, g[i]);
+    if (has_full) for (long long t = tf + tid; t < tl; t += kPeakThreads) mn = fminf(mn, stats[t].x);
+    mn = wave_min(mn);
+    if (lane == 0) red[wv] = mn;
+    __syncthreads();
+    if (tid == 0) seg_min_s = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    __syncthreads();
+    const float seg_min = seg_min_s;
+
+    // ---- pieces: head, full tiles, tail ------------------------------------
+    const long long npieces = (has_full ? (tl - tf) : 0) + 2;
+    for (long long pc = 0; pc < npieces; ++pc) {
+        long long lo, hi;
+        if (pc == 0) { lo = a; hi = head_hi; }
+        else if (pc == npieces - 1) { lo = tail_lo; hi = b; }
+        else {
+            const long long t = tf + (pc - 1);
+            lo = t * kTile; hi = lo + kTile;
+            // prominence <= height - chunk_min (monotone f32 rounding), so a tile
+            // whose maximum fails the test cannot hold a qualifying peak
+            if (!((stats[t].y - seg_min) >= min_prom)) continue;
+        }
+        if (hi <= lo) continue;
+        // -- local maxima with flat tops whose height can qualify --
+        for (long long i = lo + tid; i < hi; i += kPeakThreads) {
+            if (i <= a || i >= b - 1) continue;
+            const float x = g[i];
+            if (!(g[i - 1] < x) || !((x - seg_min) >= min_prom)) continue;
+            long long k = i + 1;
+            while (k < b - 1 && g[k] == x) ++k;
+            if (g[k] < x) {
+                const int slot = atomicAdd(&queue_n, 1);
+                if (slot < kQueueCap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
+                else overflow = 1;
+            }
+        }
+        __syncthreads();
+        const int qn = queue_n < kQueueCap ? queue_n : kQueueCap;
+        // -- prominence, one wavefront per candidate --
+        for (int q = wv; q < qn; q += kWaves) {
+            const Cand cd = queue[q];
+            float prom = 0.0f;
+            const bool keep = prominence(g, stats, a, b, cd.ps, cd.pe, cd.h, min_prom, lane, prom);
+            if (keep && lane == 0) {
+                const int slot = atomicAdd(&res_n, 1);
+                if (slot < AM_MAX_PEAKS_PER_CHUNK) {
+                    res[slot].start = (uint64_t)cd.ps; res[slot].end = (uint64_t)cd.pe;
+                    res[slot].height = cd.h; res[slot].prominence = prom;
+                } else overflow = 1;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) queue_n = 0;
+        __syncthreads();
+    }
+
+    // ---- order by height descending (ties: position ascending) -------------
+    const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
+    for (int i = tid; i < rn; i += kPeakThreads) {
+        const float hi_ = res[i].height; const uint64_t si = res[i].start;
+        int rank = 0;
+        for (int j = 0; j < rn; ++j) {
+            const float hj = res[j].height;
+            if (hj > hi_ || (hj == hi_ && res[j].start < si)) ++rank;
+        }
+        order[rank] = i;
+    }
+    __syncthreads();
+    // ---- min_distance: greedy by descending height (serial, rn is small) ----
+    if (tid == 0) {
+        int kept = 0;
+        for (int r = 0; r < rn; ++r) {
+            const am_peak pk = res[order[r]];
+            const long long mid = (long long)((pk.start + pk.end) / 2);
+            bool ok = true;
+            if (min_dist > 0) {
+                for (int k = 0; k < kept && ok; ++k) {
+                    const long long mk = (long long)((my_out[k].start + my_out[k].end) / 2);
+                    const long long d = mid > mk ? mid - mk : mk - mid;
+                    if (d < min_dist) ok = false;
+                }
+            }
+            if (ok) my_out[kept++] = pk;
+        }
+        out_n[blockIdx.x] = kept;
+        if (overflow) atomicExch(err, 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sum of squares in f64 (CorrelateAlgo::inverse_sample_auto_correlation,
+// audio_matcher.rs:321-329: element 0 of the needle's autocorrelation)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, long long n, double* out) {
+    __shared__ double part[4];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double v = (double)x[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+
+// counter-based test signal; must stay bit-identical to
+// orc_synth_uniform in oracle/oracle.c
+__global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ out, uint32_t seed, uint32_t stream,
+                                                    uint64_t first, long long n, float amp) {
+    const uint32_t key = fmix32(seed * 0x9E3779B9u + stream * 0x7F4A7C15u + 0x01234567u);
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+        const uint64_t i = first + (uint64_t)k;
+        uint32_t h = fmix32((uint32_t)i ^ key);
+        h = fmix32(h + stream * 0x9E3779B9u + (uint32_t)(i >> 32) * 0xC2B2AE35u + seed);
+        const int32_t v = (int32_t)(h >> 8) - (1 << 23);
+        out[k] = ((float)v * (1.0f / 8388608.0f)) * amp;
+    }
+}
+
+__global__ void __launch_bounds__(256) axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, float gain) {
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256)
+        dst[k] = __fadd_rn(dst[k], __fmul_rn(gain, src[k]));
+}
+
+// mp3_reader.rs:12, 28-37: (l as f32 + r as f32) * 0.5 * PCM_FACTOR, each step in f32
+__global__ void __launch_bounds__(256) pcm_downmix_kernel(const int16_t* __restrict__ in, long long frames, float* __restrict__ out) {
+    const float pcm_factor = 1.0f / 65535.0f;
+    const short2* in2 = reinterpret_cast<const short2*>(in);
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < frames; k += (long long)gridDim.x * 256) {
+        const short2 lr = in2[k];
+        const float sum = __fadd_rn((float)lr.x, (float)lr.y);
+        out[k] = __fmul_rn(__fmul_rn(sum, 0.5f), pcm_factor);
+    }
+}
+
+static inline int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats) {
+    const long long tiles = (n + kTile - 1) / kTile;
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_stats, dim3((unsigned)tiles), dim3(256), 0, st, g, n, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
+                        const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
+                        am_peak* d_out, int* d_out_n, int* d_err) {
+    if (nsegs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
+                       min_prom, min_dist, d_out, d_out_n, d_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_out) {
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(double), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
+                        long long n, float amp) {
+    hipLaunchKernelGGL(synth_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, seed, stream, first, n, amp);
+    return hipGetLastError();
+}
+
+hipError_t launch_axpy(hipStream_t st, float* dst, const float* src, long long n, float gain) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, src, n, gain);
+    return hipGetLastError();
+}
+
+hipError_t launch_pcm_downmix(hipStream_t st, const int16_t* in, long long frames, float* out) {
+    hipLaunchKernelGGL(pcm_downmix_kernel, dim3(grid_for(frames)), dim3(256), 0, st, in, frames, out);
+    return hipGetLastError();
+}
+
+}  // namespace am

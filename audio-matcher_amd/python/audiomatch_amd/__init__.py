@@ -1,0 +1,347 @@
+"""ctypes host binding of libaudiomatch_amd.so (MI355X / gfx950).
+
+Mirrors the reference's matcher interface (src/matcher/audio_matcher.rs):
+
+    LibConvolve::new(sample)                 -> HipConvolve(sample)
+    algo.inverse_sample_auto_correlation()   -> HipConvolve.inverse_sample_auto_correlation()
+    algo.correlate_with_sample(w, mode, sc)  -> HipConvolve.correlate_with_sample(w, mode, scale)
+    calc_chunks(sr, samples, &algo, scale, config)
+                                             -> calc_chunks(sr, samples, algo, scale, config)
+
+Every call goes through the C ABI of include/audiomatch.h; there is no Python
+or CPU implementation behind it.  Importing this module fails loudly when the
+HIP library is missing or cannot be loaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.abspath(os.path.join(_PKG, "..", ".."))
+LIB_PATH = os.path.join(_ROOT, "libaudiomatch_amd.so")
+
+AM_OK, AM_ERR_INVALID_ARG, AM_ERR_CAPACITY, AM_ERR_HIP, AM_ERR_NO_DEVICE, \
+    AM_ERR_PEAK_OVERFLOW, AM_ERR_OOM = range(7)
+AM_MAX_PEAKS_PER_CHUNK = 1024
+
+
+class Mode(enum.IntEnum):          # audio_matcher.rs:55-59
+    Full = 0
+    Same = 1
+    Valid = 2
+
+
+class Scale(enum.IntEnum):
+    NONE = 0
+    LIB = 1                        # LibConvolve, production (audio_matcher.rs:306-308)
+    MY = 2                         # MyConvolve (audio_matcher.rs:442-448)
+
+
+class AmPeak(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64),
+                ("height", C.c_float), ("prominence", C.c_float)]
+
+
+class AmMatchParams(C.Structure):
+    _fields_ = [("sr", C.c_uint32), ("chunk", C.c_uint64), ("overlap", C.c_uint64),
+                ("min_prominence", C.c_float), ("min_distance", C.c_uint64),
+                ("overshadow_distance_s", C.c_double), ("scale", C.c_int)]
+
+
+class AudioMatchError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"audiomatch error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/audiomatch.h declares: (name, restype, argtypes)
+_f32p = C.POINTER(C.c_float)
+_SIGNATURES = {
+    "am_abi_version": (C.c_int, []),
+    "am_last_error_string": (C.c_char_p, []),
+    "am_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "am_needle_create": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "am_needle_create_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "am_needle_destroy": (None, [C.c_void_p]),
+    "am_needle_len": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "am_needle_inv_autocorr": (C.c_int, [C.c_void_p, _f32p]),
+    "am_correlate_len": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]),
+    "am_correlate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                               C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_correlate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AmMatchParams),
+                           C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AmMatchParams),
+                                  C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                        C.c_size_t, C.POINTER(AmMatchParams), C.POINTER(AmPeak),
+                                        C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_find_peaks": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64,
+                                C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_pcm_s16_stereo_to_mono": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "am_pcm_s16_stereo_to_mono_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "am_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "am_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "am_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "am_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "am_device_synchronize": (C.c_int, [C.c_int]),
+    "am_synth_uniform_device": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
+                                          C.c_size_t, C.c_float]),
+    "am_axpy_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "am_profile_enable": (C.c_int, [C.c_int, C.c_int]),
+    "am_profile_reset": (C.c_int, [C.c_int]),
+    "am_profile_query": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "am_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "am_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (no fallback: raises if it is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python audio-matcher_amd/build.py` "
+                "(__graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != AM_OK:
+        msg = lib().am_last_error_string()
+        raise AudioMatchError(rc, msg.decode() if msg else "")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().am_device_count(C.byref(n))
+    return n.value if rc == AM_OK else 0
+
+
+def set_option(key: str, value: int):
+    _check(lib().am_set_option(key.encode(), int(value)))
+
+
+def get_option(key: str) -> int:
+    v = C.c_longlong(0)
+    _check(lib().am_get_option(key.encode(), C.byref(v)))
+    return v.value
+
+
+# ---------------------------------------------------------------------------
+class DeviceBuffer:
+    """A raw HBM allocation owned through the C ABI (am_device_malloc)."""
+
+    def __init__(self, device: int, nbytes: int):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        _check(lib().am_device_malloc(device, max(self.nbytes, 4), C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, device: int, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        buf = cls(device, a.nbytes)
+        if a.nbytes:
+            _check(lib().am_memcpy_h2d(device, buf.ptr, a.ctypes.data, a.nbytes))
+        return buf
+
+    def to_numpy(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            _check(lib().am_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().am_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synth_uniform_device(device: int, n: int, seed: int, stream: int, first: int = 0,
+                         amp: float = 0.25) -> DeviceBuffer:
+    buf = DeviceBuffer(device, n * 4)
+    _check(lib().am_synth_uniform_device(device, buf.ptr, seed, stream, first, n, amp))
+    return buf
+
+
+def axpy_device(device: int, dst: DeviceBuffer, dst_offset: int, src_ptr: int, n: int, gain: float = 1.0):
+    _check(lib().am_axpy_device(device, dst.ptr + 4 * dst_offset, src_ptr, n, gain))
+
+
+def pcm_s16_stereo_to_mono(interleaved: np.ndarray, device: int = 0) -> np.ndarray:
+    """mp3_reader.rs:28-37 down-mix on the GPU."""
+    a = np.ascontiguousarray(interleaved, dtype=np.int16)
+    frames = a.size // 2
+    out = np.empty(frames, dtype=np.float32)
+    _check(lib().am_pcm_s16_stereo_to_mono(device, a.ctypes.data, frames, out.ctypes.data))
+    return out
+
+
+def find_peaks(y_data, min_prominence: float, min_distance: int = 0, device: int = 0, cap: int = 65536):
+    """audio_matcher.rs:221-230 on the GPU; peaks by descending height."""
+    a = np.ascontiguousarray(y_data, dtype=np.float32)
+    buf = (AmPeak * cap)()
+    n = C.c_size_t(0)
+    _check(lib().am_find_peaks(device, a.ctypes.data, a.size, float(min_prominence), int(min_distance),
+                               buf, cap, C.byref(n)))
+    return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
+
+
+# ---------------------------------------------------------------------------
+@dataclass
+class Peak:
+    """find_peaks::Peak<f32> as used downstream (position, height, prominence)."""
+    start: int
+    end: int
+    height: float
+    prominence: float
+
+    @property
+    def position(self):
+        return range(self.start, self.end)
+
+
+@dataclass
+class Config:
+    """audio_matcher.rs:25-53 (Config + PeakConfig), durations in seconds."""
+    chunk_size_s: float = 60.0          # matcher/args.rs:70-72
+    overlap_length_s: float = 0.0       # Config::from_args sets it to the snippet duration (:41)
+    distance_s: float = 8 * 60.0        # matcher/args.rs:73-76
+    prominence: float = 13.0 / 100.0    # args.prominence / 100 (:44), default 13 (args.rs:19)
+
+    def params(self, sr: int, scale: int) -> AmMatchParams:
+        def rnd(x):                     # f64::round: half away from zero (audio_matcher.rs:99-100)
+            return int(np.floor(x + 0.5))
+        return AmMatchParams(
+            sr=sr, chunk=rnd(self.chunk_size_s * sr), overlap=rnd(self.overlap_length_s * sr),
+            min_prominence=self.prominence,
+            min_distance=int(self.distance_s) * sr,          # distance.as_secs() as usize * sr (:228)
+            overshadow_distance_s=self.distance_s, scale=int(scale))
+
+
+class HipConvolve:
+    """CorrelateAlgo<f32> (audio_matcher.rs:65-76) backed by the HIP library."""
+
+    def __init__(self, sample_data, device: int = 0):
+        a = np.ascontiguousarray(sample_data, dtype=np.float32)
+        self.device = device
+        self._h = C.c_void_p()
+        _check(lib().am_needle_create(device, a.ctypes.data, a.size, C.byref(self._h)))
+        self.sample_len = int(a.size)
+
+    @classmethod
+    def from_device(cls, device: int, ptr: int, n: int) -> "HipConvolve":
+        self = cls.__new__(cls)
+        self.device = device
+        self._h = C.c_void_p()
+        _check(lib().am_needle_create_device(device, ptr, n, C.byref(self._h)))
+        self.sample_len = int(n)
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().am_needle_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def inverse_sample_auto_correlation(self) -> float:
+        v = C.c_float(0)
+        _check(lib().am_needle_inv_autocorr(self._h, C.byref(v)))
+        return v.value
+
+    def correlate_with_sample(self, within, mode: Mode = Mode.Valid, scale=False) -> np.ndarray:
+        """scale: bool as in the reference (True = production/LibConvolve) or a Scale value."""
+        w = np.ascontiguousarray(within, dtype=np.float32)
+        sc = int(Scale.LIB if scale is True else Scale.NONE if scale is False else scale)
+        n = C.c_size_t(0)
+        _check(lib().am_correlate_len(w.size, self.sample_len, int(mode), C.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        _check(lib().am_correlate(self._h, w.ctypes.data, w.size, int(mode), sc,
+                                  out.ctypes.data, out.size, C.byref(n)))
+        return out
+
+    # -- level 2 --
+    def match(self, haystack, params: AmMatchParams, cap: int = 4096):
+        h = np.ascontiguousarray(haystack, dtype=np.float32)
+        buf = (AmPeak * cap)()
+        n = C.c_size_t(0)
+        _check(lib().am_match(self._h, h.ctypes.data, h.size, C.byref(params), buf, cap, C.byref(n)))
+        return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
+
+    def match_device(self, ptr: int, length: int, params: AmMatchParams, cap: int = 4096):
+        buf = (AmPeak * cap)()
+        n = C.c_size_t(0)
+        _check(lib().am_match_device(self._h, ptr, length, C.byref(params), buf, cap, C.byref(n)))
+        return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
+
+    def match_batch_device(self, ptrs, lengths, params: AmMatchParams, cap_per_hay: int = 256):
+        k = len(ptrs)
+        arr_p = (C.c_void_p * k)(*ptrs)
+        arr_l = (C.c_size_t * k)(*lengths)
+        buf = (AmPeak * (cap_per_hay * k))()
+        counts = (C.c_size_t * k)()
+        _check(lib().am_match_batch_device(self._h, arr_p, arr_l, k, C.byref(params), buf,
+                                           cap_per_hay, counts))
+        out = []
+        for i in range(k):
+            sl = buf[i * cap_per_hay: i * cap_per_hay + counts[i]]
+            out.append([Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in sl])
+        return out
+
+
+def calc_chunks(sr: int, m_samples, algo_with_sample: HipConvolve, scale: bool, config: Config):
+    """audio_matcher.rs:88-141 on the GPU: returns peaks sorted by position.start."""
+    params = config.params(sr, Scale.LIB if scale else Scale.NONE)
+    return algo_with_sample.match(m_samples, params)
+
+
+class Profile:
+    """HIP-event timing of the pipeline kernels (am_profile_*)."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    def __enter__(self):
+        _check(lib().am_profile_reset(self.device))
+        _check(lib().am_profile_enable(self.device, 1))
+        return self
+
+    def __exit__(self, *exc):
+        _check(lib().am_profile_enable(self.device, 0))
+
+    def query(self, kernel: str):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(lib().am_profile_query(self.device, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,126 @@
+"""GPU parity of level 2 (calc_chunks, audio_matcher.rs:88-141) against the
+oracle on seeded synthetic audio, through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SR = 44100
+TOL = 1e-4
+
+
+def synth_case(oracle, sr, needle_s, hay_s, plants_s, seed=1, stream=1, gain=1.0):
+    s = oracle.round_samples(needle_s, sr)
+    h = oracle.round_samples(hay_s, sr)
+    needle = oracle.synth_uniform(seed, 0, 0, s)
+    hay = oracle.synth_uniform(seed, stream, 0, h)
+    for t in plants_s:
+        off = oracle.round_samples(t, sr)
+        n = min(s, h - off)
+        hay[off:off + n] += gain * needle[:n]
+    return needle, hay
+
+
+def run_both(gpu, oracle, needle, hay, sr, chunk_s, overlap_s, prom, dist_s):
+    cfg = gpu.Config(chunk_size_s=chunk_s, overlap_length_s=overlap_s, distance_s=dist_s, prominence=prom)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    got = algo.match(hay, p)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, prom, p.min_distance, dist_s,
+                             scale=oracle.SCALE_LIB)
+    return got, exp
+
+
+def assert_same(got, exp):
+    assert [g.start for g in got] == [e[0] for e in exp]      # identical integer offsets
+    assert [g.end for g in got] == [e[1] for e in exp]
+    for g, e in zip(got, exp):
+        assert abs(g.height - e[2]) < TOL
+        assert abs(g.prominence - e[3]) < TOL
+
+
+def test_config1_10s_needle_60s_haystack(gpu, oracle):
+    """BASELINE config 1: 10 s needle vs 60 s haystack, one plant at 20 s."""
+    needle, hay = synth_case(oracle, SR, 10.0, 60.0, [20.0])
+    got, exp = run_both(gpu, oracle, needle, hay, SR, 60.0, 10.0, 0.13, 480.0)
+    assert [e[0] for e in exp] == [20 * SR]
+    assert_same(got, exp)
+
+
+def test_multi_chunk_with_tail_and_overshadow(gpu, oracle):
+    """3.5 chunks of 20 s, plants in different chunks, two closer than `distance`
+    (the weaker one is overshadowed, audio_matcher.rs:143-160)."""
+    sr = 8000
+    needle, hay = synth_case(oracle, sr, 2.0, 70.0, [5.0, 31.0, 64.5], seed=7)
+    # weaker copy 3 s after the first plant: survives find_peaks only if in another chunk
+    off = oracle.round_samples(22.0, sr)
+    hay[off:off + needle.size] += 0.5 * needle
+    got, exp = run_both(gpu, oracle, needle, hay, sr, 20.0, 2.0, 0.13, 25.0)
+    assert len(exp) >= 2
+    assert_same(got, exp)
+
+
+def test_peak_on_chunk_boundary_region(gpu, oracle):
+    """A plant whose peak sits in the 1-sample overlap between two chunks' score
+    slices is a chunk edge in both and reported by neither; one sample later it
+    is found by the second chunk."""
+    sr = 8000
+    for delta in (0, 1, -1):
+        needle, hay = synth_case(oracle, sr, 1.0, 30.0, [], seed=3)
+        off = 10 * sr + delta
+        hay[off:off + needle.size] += needle
+        got, exp = run_both(gpu, oracle, needle, hay, sr, 10.0, 1.0, 0.13, 480.0)
+        assert_same(got, exp)
+
+
+def test_no_hit_and_short_haystack(gpu, oracle):
+    sr = 8000
+    needle, hay = synth_case(oracle, sr, 1.0, 12.0, [], seed=5)
+    got, exp = run_both(gpu, oracle, needle, hay, sr, 5.0, 1.0, 0.13, 480.0)
+    assert got == [] and exp == []
+    # haystack shorter than the needle: no window holds a complete needle
+    got, exp = run_both(gpu, oracle, needle, hay[:needle.size - 1], sr, 5.0, 1.0, 0.13, 480.0)
+    assert got == [] and exp == []
+
+
+def test_small_distance_many_peaks_per_chunk(gpu, oracle):
+    sr = 8000
+    needle, hay = synth_case(oracle, sr, 0.5, 40.0, [1.0, 4.0, 9.5, 13.0, 22.2, 30.0, 38.0], seed=9)
+    got, exp = run_both(gpu, oracle, needle, hay, sr, 15.0, 0.5, 0.4, 2.0)
+    assert len(exp) == 7
+    assert_same(got, exp)
+
+
+def test_device_resident_and_batch(gpu, oracle):
+    sr = 8000
+    needle, hay1 = synth_case(oracle, sr, 1.0, 40.0, [3.0, 33.0], seed=11, stream=1)
+    _, hay2 = synth_case(oracle, sr, 1.0, 25.0, [12.5], seed=11, stream=2)
+    cfg = gpu.Config(chunk_size_s=10.0, overlap_length_s=1.0, distance_s=5.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    b1 = gpu.DeviceBuffer.from_numpy(0, hay1)
+    b2 = gpu.DeviceBuffer.from_numpy(0, hay2)
+    res = algo.match_batch_device([b1.ptr, b2.ptr], [hay1.size, hay2.size], p)
+    for r, hay in zip(res, (hay1, hay2)):
+        exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+        assert_same(r, exp)
+    assert [x.start for x in res[0]] == [3 * sr, 33 * sr]
+    assert [x.start for x in res[1]] == [int(12.5 * sr)]
+
+
+def test_synth_generator_matches_oracle_bitwise(gpu, oracle):
+    n = 100_003
+    buf = gpu.synth_uniform_device(0, n, seed=3, stream=17, first=12345, amp=0.25)
+    got = buf.to_numpy(np.float32, n)
+    exp = oracle.synth_uniform(3, 17, 12345, n, 0.25)
+    assert np.array_equal(got, exp)
+
+
+def test_pcm_downmix_bit_exact(gpu, oracle):
+    """mp3_reader.rs:28-37: (l + r) * 0.5 * (1/65535) in f32, bit for bit."""
+    rng = np.random.default_rng(0)
+    lr = rng.integers(-32768, 32768, size=2 * 100_001, dtype=np.int16)
+    lr[:8] = [32767, 32767, -32768, -32768, 32767, -32768, 0, 1]
+    got = gpu.pcm_s16_stereo_to_mono(lr)
+    exp = oracle.pcm_s16_stereo_to_mono(lr)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
