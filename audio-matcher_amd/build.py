@@ -20,7 +20,7 @@ SOURCES = ["am_fft.hip", "am_peaks.hip", "am_api.hip"]
 HEADERS = [os.path.join(CSRC, "am_kernels.h"),
            os.path.join(HERE, "..", "include", "audiomatch.h")]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-result"]
 
 

@@ -43,7 +43,7 @@ static int hip_fail(hipError_t e, const char* what) {
 
 // tuning knobs
 static long long g_opt_log_n = 0;          // 0 = auto
-static long long g_opt_pairs_per_group = 4;
+static long long g_opt_pairs_per_group = 64;
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
 
@@ -93,7 +93,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, scores, stats, segs, peaks, counts, io_in, io_out, sum;
+    DevBuf work, scores, stats, stats32, segs, hdr, peaks, counts, io_in, io_out, sum;
     HostBuf pinned;
     // profiling
     bool prof = false;
@@ -256,8 +256,11 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
 }
 
 // The overlap-save engine: scores[j] = factor * sum_n X[j + n - lead] needle[n]
+// When want_stats is set and the plan supports it, K3 also writes the level-0
+// (min,max) summary into c->stats32 and *have_stats becomes true.
 static int run_correlation(am_needle* h, const float* d_src, long long src_len, long long lead,
-                           float* d_dst, long long out_count, float factor) {
+                           float* d_dst, long long out_count, float factor,
+                           bool want_stats = false, bool* have_stats = nullptr) {
     Ctx* c = h->ctx;
     int logN = 0;
     int rc = pick_log_n(h->n, out_count, &logN);
@@ -274,6 +277,13 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
     long long ppg = std::max<long long>(1, g_opt_pairs_per_group);
     if (ppg > npairs) ppg = npairs;
     if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
+    float2* stats32 = nullptr;
+    if (have_stats) *have_stats = false;
+    if (want_stats && plan_is_r16(pl->dev) && (hop % kTile) == 0) {
+        if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
+        stats32 = (float2*)c->stats32.p;
+        if (have_stats) *have_stats = true;
+    }
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
@@ -282,7 +292,7 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
         job.first_pair = (int)first;
         { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev)); }
         { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev)); }
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, factor)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, factor, stats32)); }
     }
     return AM_OK;
 }
@@ -328,64 +338,33 @@ static bool is_overshadowed(const am_peak& element, const am_peak* other, uint32
     return (e - b) < maxd && other->prominence > element.prominence;
 }
 
-// find_peaks (audio_matcher.rs:221-230) on every segment of a resident score
-// array; results are appended segment by segment, each by descending height.
-static int pick_peaks(Ctx* c, const float* d_scores, long long n_scores, const std::vector<Segment>& segs,
-                      float min_prom, long long min_dist, std::vector<am_peak>& all) {
-    const int nsegs = (int)segs.size();
+// Launches find_peaks (audio_matcher.rs:221-230) for `nsegs` segments of a
+// resident score array; segment descriptors and result headers live at
+// [seg_off, seg_off + nsegs) of the context's segment / header buffers.
+static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
+                       float min_prom, long long min_dist, const float2* d_stats32) {
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;
     if ((rc = c->stats.ensure((size_t)ntiles * sizeof(float2)))) return rc;
-    { ProfScope ps(c, KN_STATS); AM_HIP(launch_tile_stats(c->stream, d_scores, n_scores, (float2*)c->stats.p)); }
-    const size_t seg_bytes = sizeof(Segment) * nsegs;
-    const size_t cnt_bytes = sizeof(int) * (nsegs + 1);
-    if ((rc = c->segs.ensure(seg_bytes))) return rc;
-    if ((rc = c->counts.ensure(cnt_bytes))) return rc;
-    if ((rc = c->peaks.ensure(sizeof(am_peak) * (size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
-    if ((rc = c->pinned.ensure(std::max(seg_bytes, cnt_bytes) + 64))) return rc;
-    memcpy(c->pinned.p, segs.data(), seg_bytes);
-    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, seg_bytes, hipMemcpyHostToDevice, c->stream));
-    AM_HIP(hipMemsetAsync(c->counts.p, 0, cnt_bytes, c->stream));
-    int* d_counts = (int*)c->counts.p;
-    int* d_err = d_counts + nsegs;
+    {
+        ProfScope ps(c, KN_STATS);
+        if (d_stats32) AM_HIP(launch_stats_reduce(c->stream, d_stats32, n_scores, (float2*)c->stats.p));
+        else AM_HIP(launch_tile_stats(c->stream, d_scores, n_scores, (float2*)c->stats.p));
+    }
     {
         ProfScope ps(c, KN_PEAKS);
         AM_HIP(launch_peaks(c->stream, d_scores, n_scores, (const float2*)c->stats.p,
-                            (const Segment*)c->segs.p, nsegs, min_prom, min_dist,
-                            (am_peak*)c->peaks.p, d_counts, d_err));
-    }
-    AM_HIP(hipStreamSynchronize(c->stream));
-    std::vector<int> counts(nsegs + 1);
-    AM_HIP(hipMemcpy(counts.data(), d_counts, cnt_bytes, hipMemcpyDeviceToHost));
-    if (counts[nsegs]) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-    for (int i = 0; i < nsegs; ++i) {
-        if (counts[i] <= 0) continue;
-        const size_t old = all.size();
-        all.resize(old + counts[i]);
-        AM_HIP(hipMemcpy(all.data() + old, (am_peak*)c->peaks.p + (size_t)i * AM_MAX_PEAKS_PER_CHUNK,
-                         sizeof(am_peak) * counts[i], hipMemcpyDeviceToHost));
+                            (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
+                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p + seg_off));
     }
     return AM_OK;
 }
 
-// calc_chunks on a resident haystack (audio_matcher.rs:88-141)
-static int match_device(am_needle* h, const float* d_hay, size_t len, const am_match_params* p,
-                        am_peak* out, size_t cap, size_t* n_out) {
-    Ctx* c = h->ctx;
-    const size_t s = h->n;
-    *n_out = 0;
-    if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
-    if (len < s) return AM_OK;  // no window holds a complete needle
-    const long long out_count = (long long)(len - s + 1);
-    int rc;
-    if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
-    if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
-        return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB (AM_SCALE_MY depends on the window length)");
-    const float factor = scale_factor(h, p->scale, 1);
-    if ((rc = run_correlation(h, d_hay, (long long)len, 0, (float*)c->scores.p, out_count, factor))) return rc;
-    // windows: common::chunked(chunk + overlap, hop = chunk) (audio_matcher.rs:104)
-    std::vector<Segment> segs;
+// windows of common::chunked(chunk + overlap, hop = chunk) (audio_matcher.rs:104)
+// as slices of the global score array; a window shorter than the needle has
+// no valid lag and is skipped.
+static void make_segments(size_t len, size_t s, const am_match_params* p, std::vector<Segment>& segs) {
     const unsigned long long window = p->chunk + p->overlap;
     for (unsigned long long off = 0; off < len; off += p->chunk) {
         const unsigned long long w = std::min<unsigned long long>(window, len - off);
@@ -393,13 +372,11 @@ static int match_device(am_needle* h, const float* d_hay, size_t len, const am_m
         Segment sg; sg.a = (long long)off; sg.b = (long long)(off + w - s + 1);
         segs.push_back(sg);
     }
-    // per-chunk find_peaks, collected in window order (audio_matcher.rs:124-133)
-    std::vector<am_peak> all;
-    if ((rc = pick_peaks(c, (const float*)c->scores.p, out_count, segs, p->min_prominence,
-                         (long long)p->min_distance, all))) return rc;
-    // sorted_by position.start, stable (audio_matcher.rs:135)
+}
+
+// sort by start (audio_matcher.rs:135) + filter_surrounding (audio_matcher.rs:136-139)
+static int merge_peaks(std::vector<am_peak>& all, const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
     std::stable_sort(all.begin(), all.end(), [](const am_peak& x, const am_peak& y) { return x.start < y.start; });
-    // filter_surrounding (audio_matcher.rs:136-139): neighbours of the sorted, unfiltered sequence
     size_t n = 0;
     for (size_t i = 0; i < all.size(); ++i) {
         const am_peak* before = i > 0 ? &all[i - 1] : nullptr;
@@ -412,6 +389,115 @@ static int match_device(am_needle* h, const float* d_hay, size_t len, const am_m
     }
     *n_out = n;
     if (n > cap) return fail(AM_ERR_CAPACITY, "peak output buffer too small");
+    return AM_OK;
+}
+
+// calc_chunks (audio_matcher.rs:88-141) over a batch of resident haystacks =
+// the per-file loop of matcher::run (matcher/mod.rs:42-87).  Everything is
+// queued on the context's stream without host synchronisation; one small
+// device-to-host copy of the per-chunk headers ends the batch.
+static int match_many(am_needle* h, const float* const* d_hays, const size_t* lens, size_t n_hay,
+                      const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    Ctx* c = h->ctx;
+    const size_t s = h->n;
+    if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
+    if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
+        return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB (AM_SCALE_MY depends on the window length)");
+    const float factor = scale_factor(h, p->scale, 1);
+    std::vector<Segment> segs;
+    std::vector<int> seg_off(n_hay + 1, 0);
+    size_t max_scores = 0, max_segs = 0;
+    for (size_t k = 0; k < n_hay; ++k) {
+        n_out[k] = 0;
+        seg_off[k] = (int)segs.size();
+        if (d_hays[k] && lens[k] >= s) {
+            make_segments(lens[k], s, p, segs);
+            max_scores = std::max(max_scores, lens[k] - s + 1);
+        }
+        max_segs = std::max(max_segs, segs.size() - (size_t)seg_off[k]);
+    }
+    seg_off[n_hay] = (int)segs.size();
+    const size_t nsegs = segs.size();
+    if (nsegs == 0) return AM_OK;
+    int rc;
+    const size_t seg_bytes = sizeof(Segment) * nsegs, hdr_bytes = sizeof(SegHeader) * nsegs;
+    if ((rc = c->scores.ensure(max_scores * sizeof(float)))) return rc;
+    if ((rc = c->segs.ensure(seg_bytes))) return rc;
+    if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
+    if ((rc = c->peaks.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    if ((rc = c->pinned.ensure(seg_bytes + hdr_bytes + 64))) return rc;
+    memcpy(c->pinned.p, segs.data(), seg_bytes);
+    SegHeader* h_hdr = reinterpret_cast<SegHeader*>(static_cast<char*>(c->pinned.p) + ((seg_bytes + 63) & ~(size_t)63));
+    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, seg_bytes, hipMemcpyHostToDevice, c->stream));
+    for (size_t k = 0; k < n_hay; ++k) {
+        const int ns = seg_off[k + 1] - seg_off[k];
+        if (ns == 0) continue;
+        const long long out_count = (long long)(lens[k] - s + 1);
+        bool have_stats = false;
+        if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
+                                  true, &have_stats))) return rc;
+        if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, seg_off[k], ns, p->min_prominence,
+                              (long long)p->min_distance, have_stats ? (const float2*)c->stats32.p : nullptr))) return rc;
+    }
+    AM_HIP(hipMemcpyAsync(h_hdr, c->hdr.p, hdr_bytes, hipMemcpyDeviceToHost, c->stream));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    int worst = AM_OK;
+    std::vector<am_peak> all;
+    for (size_t k = 0; k < n_hay; ++k) {
+        const int s0 = seg_off[k], s1 = seg_off[k + 1];
+        if (s1 == s0) continue;
+        bool big = false;
+        for (int i = s0; i < s1; ++i) {
+            if (h_hdr[i].overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+            if (h_hdr[i].n > kInlinePeaks) big = true;
+        }
+        all.clear();
+        if (!big) {
+            // collect in window order (audio_matcher.rs:132-133)
+            for (int i = s0; i < s1; ++i)
+                for (int j = 0; j < h_hdr[i].n; ++j) all.push_back(h_hdr[i].first[j]);
+        } else {
+            // rare: a chunk with more peaks than a header holds; its full list was
+            // overwritten by later haystacks, so redo this haystack on its own
+            const long long out_count = (long long)(lens[k] - s + 1);
+            bool have_stats = false;
+            if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
+                                      true, &have_stats))) return rc;
+            if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, s0, s1 - s0, p->min_prominence,
+                                  (long long)p->min_distance, have_stats ? (const float2*)c->stats32.p : nullptr))) return rc;
+            AM_HIP(hipStreamSynchronize(c->stream));
+            for (int i = s0; i < s1; ++i) {
+                const int cnt = h_hdr[i].n;
+                if (cnt <= 0) continue;
+                const size_t old = all.size();
+                all.resize(old + cnt);
+                AM_HIP(hipMemcpy(all.data() + old, (am_peak*)c->peaks.p + (size_t)(i - s0) * AM_MAX_PEAKS_PER_CHUNK,
+                                 sizeof(am_peak) * cnt, hipMemcpyDeviceToHost));
+            }
+        }
+        rc = merge_peaks(all, p, out ? out + k * cap_per_hay : nullptr, cap_per_hay, &n_out[k]);
+        if (rc == AM_ERR_CAPACITY) worst = rc;
+        else if (rc) return rc;
+    }
+    return worst;
+}
+
+// find_peaks on one host score array (am_find_peaks)
+static int find_peaks_host_array(Ctx* c, const float* d_scores, long long n, float min_prom, long long min_dist,
+                                 std::vector<am_peak>& all) {
+    int rc;
+    Segment sg; sg.a = 0; sg.b = n;
+    if ((rc = c->segs.ensure(sizeof(Segment)))) return rc;
+    if ((rc = c->hdr.ensure(sizeof(SegHeader)))) return rc;
+    if ((rc = c->peaks.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    AM_HIP(hipMemcpy(c->segs.p, &sg, sizeof(sg), hipMemcpyHostToDevice));
+    if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr))) return rc;
+    AM_HIP(hipStreamSynchronize(c->stream));
+    SegHeader hd;
+    AM_HIP(hipMemcpy(&hd, c->hdr.p, sizeof(hd), hipMemcpyDeviceToHost));
+    if (hd.overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+    all.resize(hd.n);
+    if (hd.n > 0) AM_HIP(hipMemcpy(all.data(), c->peaks.p, sizeof(am_peak) * hd.n, hipMemcpyDeviceToHost));
     return AM_OK;
 }
 
@@ -561,7 +647,7 @@ int am_match_device(const am_needle* hc, const float* d_haystack, size_t len,
     if (!d_haystack || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
     if (len == 0) { *n_out = 0; return AM_OK; }
     std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
-    return match_device(h, d_haystack, len, p, out, cap, n_out);
+    return match_many(h, &d_haystack, &len, 1, p, out, cap, n_out);
 }
 
 int am_match(const am_needle* hc, const float* haystack, size_t len,
@@ -575,7 +661,8 @@ int am_match(const am_needle* hc, const float* haystack, size_t len,
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(len * sizeof(float)))) return rc;
     AM_HIP(hipMemcpy(c->io_in.p, haystack, len * sizeof(float), hipMemcpyHostToDevice));
-    return match_device(h, (const float*)c->io_in.p, len, p, out, cap, n_out);
+    const float* d_in = (const float*)c->io_in.p;
+    return match_many(h, &d_in, &len, 1, p, out, cap, n_out);
 }
 
 int am_match_batch_device(const am_needle* hc, const float* const* d_haystacks, const size_t* lens,
@@ -586,15 +673,8 @@ int am_match_batch_device(const am_needle* hc, const float* const* d_haystacks, 
     if (rc) return rc;
     if (!d_haystacks || !lens || !p || !n_out || (!out && cap_per_hay)) return fail(AM_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
-    int worst = AM_OK;
-    for (size_t k = 0; k < n_hay; ++k) {
-        n_out[k] = 0;
-        if (!d_haystacks[k] || lens[k] == 0) continue;
-        rc = match_device(h, d_haystacks[k], lens[k], p, out + k * cap_per_hay, cap_per_hay, &n_out[k]);
-        if (rc == AM_ERR_CAPACITY) { worst = rc; continue; }
-        if (rc) return rc;
-    }
-    return worst;
+    if (n_hay == 0) return AM_OK;
+    return match_many(h, d_haystacks, lens, n_hay, p, out, cap_per_hay, n_out);
 }
 
 int am_find_peaks(int device, const float* scores, size_t n, float min_prominence,
@@ -608,11 +688,9 @@ int am_find_peaks(int device, const float* scores, size_t n, float min_prominenc
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(n * sizeof(float)))) return rc;
     AM_HIP(hipMemcpy(c->io_in.p, scores, n * sizeof(float), hipMemcpyHostToDevice));
-    std::vector<Segment> segs(1);
-    segs[0].a = 0; segs[0].b = (long long)n;
     std::vector<am_peak> all;
-    if ((rc = pick_peaks(c, (const float*)c->io_in.p, (long long)n, segs, min_prominence,
-                         (long long)min_distance, all))) return rc;
+    if ((rc = find_peaks_host_array(c, (const float*)c->io_in.p, (long long)n, min_prominence,
+                                    (long long)min_distance, all))) return rc;
     *n_out = all.size();
     for (size_t i = 0; i < all.size() && i < cap; ++i) out[i] = all[i];
     if (all.size() > cap) return fail(AM_ERR_CAPACITY, "peak output buffer too small");

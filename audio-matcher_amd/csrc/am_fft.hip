@@ -10,22 +10,32 @@
 //
 // The N-point transform is factored N = N1 * N2 (n = n1*N2 + n2,
 // k = k1 + N1*k2) into three kernels, each of which keeps its whole sub-problem
-// in LDS and touches HBM exactly once for reading and once for writing:
+// on chip and touches HBM exactly once for reading and once for writing:
 //
-//   K1 k1_cols_fwd : 32 adjacent columns x N1 rows per workgroup; PCM->f32 load
-//                    with virtual zero padding, length-N1 column FFTs.
-//   K2 k2_rows     : one contiguous row (N2 points) per workgroup; twiddle
-//                    W_N^(n2*k1), forward row FFT, multiply by the needle
-//                    spectrum conj(H)/N, inverse row FFT, conjugate twiddle.
-//                    The spectrum never exists in HBM.
-//   K3 k3_cols_inv : inverse column FFTs, needle-energy scaling, real part ->
-//                    scores of block 2g, imaginary part -> scores of block 2g+1.
+//   K1 k1_cols_fwd : 32 adjacent columns x N1 rows per workgroup; f32 load with
+//                    virtual zero padding, length-N1 column FFTs, twiddle
+//                    W_N^(n2*k1).
+//   K2 k2_rows     : one contiguous row (N2 points) per workgroup; forward row
+//                    FFT, multiply by the needle spectrum conj(H)/N, inverse
+//                    row FFT.  The spectrum never exists in HBM.
+//   K3 k3_cols_inv : conjugate twiddle, inverse column FFTs, needle-energy
+//                    scaling, real part -> scores of block 2g, imaginary part
+//                    -> scores of block 2g+1, plus a (min,max) summary per 32
+//                    scores for the peak pick.
 //
-// Forward transforms are decimation-in-frequency (natural in, bit-reversed
-// out), inverse ones decimation-in-time (bit-reversed in, natural out), so no
-// reordering pass exists anywhere: the needle spectrum is produced by the same
-// K1/K2 code and therefore lives in the same permuted layout.
+// Two implementations of each kernel exist:
+//   *_r16 : the production shape N1 = 256, N2 = 8192 (N = 2^21).  Radix-16/32
+//           butterflies held in VGPRs, LDS used only for the exchanges between
+//           passes (conflict-free 16-byte accesses, XOR-swizzled rows), 16-byte
+//           coalesced HBM accesses, twiddles by binary powering of one table
+//           entry.
+//   *_gen : any N = 2^10 .. 2^23 (small inputs, unusual needle lengths):
+//           in-LDS radix-4 passes.
+// The needle spectrum is produced by the same K1/K2 code of the same flavour
+// and therefore always lives in the layout the multiply expects.
 #include "am_kernels.h"
+
+#include <float.h>
 
 namespace am {
 
@@ -41,6 +51,451 @@ __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
 __device__ __forceinline__ float2 mul_neg_i(float2 a) { return make_float2(a.y, -a.x); }
 __device__ __forceinline__ float2 mul_pos_i(float2 a) { return make_float2(-a.y, a.x); }
 
+// W_N^m through the two-level table of the plan (m already reduced mod N)
+__device__ __forceinline__ float2 tw_big(const PlanDev& pl, unsigned m) {
+    return cmul(pl.twhi[m >> pl.logLo], pl.twlo[m & ((1u << pl.logLo) - 1u)]);
+}
+
+// ===========================================================================
+// Register-resident radix-R DIF butterflies (R <= 32), natural order in,
+// bit-reversed order out: X[k] ends up in x[brev(k)].
+// ===========================================================================
+__device__ constexpr float kCos32[16] = {
+    1.0f, 0.9807852804032304f, 0.9238795325112867f, 0.8314696123025452f, 0.7071067811865476f,
+    0.5555702330196023f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.1950903220161282f,
+    -0.3826834323650897f, -0.555570233019602f, -0.7071067811865475f, -0.8314696123025453f,
+    -0.9238795325112867f, -0.9807852804032304f};
+__device__ constexpr float kSin32[16] = {
+    0.0f, 0.19509032201612825f, 0.3826834323650898f, 0.5555702330196022f, 0.7071067811865475f,
+    0.8314696123025452f, 0.9238795325112867f, 0.9807852804032304f, 1.0f, 0.9807852804032304f,
+    0.9238795325112867f, 0.8314696123025455f, 0.7071067811865476f, 0.5555702330196022f,
+    0.3826834323650899f, 0.1950903220161286f};
+
+template <int R>
+__host__ __device__ constexpr int brev(int i) {
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1) { r = (r << 1) | (i & 1); i >>= 1; }
+    return r;
+}
+
+// d * W_32^idx (forward) or d * conj(W_32^idx) (inverse); idx is a constant
+// after unrolling, so the trivial cases fold away.
+template <bool INV>
+__device__ __forceinline__ float2 mul_w32(float2 d, int idx) {
+    if (idx == 0) return d;
+    if (idx == 8) return INV ? mul_pos_i(d) : mul_neg_i(d);
+    const float c = kCos32[idx], s = kSin32[idx];
+    // forward twiddle = (c, -s); inverse = (c, +s)
+    if (INV) return make_float2(d.x * c - d.y * s, d.x * s + d.y * c);
+    return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void dif(float2* x) {
+    if constexpr (R >= 2) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+            const float2 a = x[i], b = x[i + R / 2];
+            x[i] = cadd(a, b);
+            x[i + R / 2] = mul_w32<INV>(csub(a, b), i * (32 / R));
+        }
+        dif<R / 2, INV>(x);
+        dif<R / 2, INV>(x + R / 2);
+    }
+}
+
+// x[brev(e)] *= w^e (or conj(w)^e), e = 1..R-1.  Powers come from balanced
+// products pw[e] = pw[ceil(e/2)] * pw[floor(e/2)] (depth log2 R, so the table
+// entry's rounding error is amplified at most R times); each power is applied
+// as soon as it exists so that only pw[1 .. R/2] stay live.
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_apply(float2* x, float2 w) {
+    float2 pw[R / 2 + 1];
+    if (CONJ) w.y = -w.y;
+    pw[1] = w;
+    x[BREV ? brev<R>(1) : 1] = cmul(x[BREV ? brev<R>(1) : 1], w);
+#pragma unroll
+    for (int e = 2; e < R; ++e) {
+        const float2 v = cmul(pw[(e + 1) / 2], pw[e / 2]);
+        if (e <= R / 2) pw[e] = v;
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], v);
+    }
+}
+template <int R, bool CONJ>
+__device__ __forceinline__ void twiddle_brev(float2* x, float2 w) { twiddle_apply<R, CONJ, true>(x, w); }
+template <int R, bool CONJ>
+__device__ __forceinline__ void twiddle_nat(float2* x, float2 w) { twiddle_apply<R, CONJ, false>(x, w); }
+
+// 16-byte buffer accesses: one VGPR of address for a whole unrolled sequence
+// (per-access offsets live in SGPRs / immediates).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+    f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
+}
+
+// ===========================================================================
+// Production kernels: N1 = 256 (16 x 16), N2 = 8192 (16 x 16 x 32), 256 threads
+// ===========================================================================
+constexpr int kR16LogN1 = 8, kR16LogN2 = 13;
+constexpr int kN2 = 1 << kR16LogN2;
+
+__device__ __forceinline__ float2 load2_padded(const float* __restrict__ src, long long i, long long len) {
+    float2 v;
+    v.x = (i >= 0 && i < len) ? src[i] : 0.0f;
+    v.y = (i + 1 >= 0 && i + 1 < len) ? src[i + 1] : 0.0f;
+    return v;
+}
+
+// K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
+// FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
+// holds frequency k1 in natural order.
+__global__ void __launch_bounds__(256, 2)
+k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
+    extern __shared__ float4 lds4[];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    const int n2_0 = blockIdx.x << kColsLog;
+    const int pair = job.first_pair + blockIdx.y;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const bool validB = blkB < job.nblocks;
+    const long long N = 1ll << pl.logN;
+    const long long baseA = blkA * job.hop - job.lead;
+    const long long baseB = blkB * job.hop - job.lead;
+    const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
+                      baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
+    float2 x0[16], x1[16];
+    // pass 1 ownership: b = hi (n1 = a*16 + b), columns 2cp, 2cp+1
+    const long long col = n2_0 + 2 * cp;
+    if (fast) {
+        const float2* __restrict__ sa = reinterpret_cast<const float2*>(job.src + baseA + col);
+        const float2* __restrict__ sb = reinterpret_cast<const float2*>(job.src + baseB + col);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const size_t off = (size_t)(a * 16 + hi) * (kN2 / 2);
+            const float2 va = sa[off], vb = sb[off];
+            x0[a] = make_float2(va.x, vb.x);
+            x1[a] = make_float2(va.y, vb.y);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            const float2 va = load2_padded(job.src, baseA + n, job.src_len);
+            const float2 vb = validB ? load2_padded(job.src, baseB + n, job.src_len) : make_float2(0.f, 0.f);
+            x0[a] = make_float2(va.x, vb.x);
+            x1[a] = make_float2(va.y, vb.y);
+        }
+    }
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    {   // W_256^(b*a')
+        const float2 w = pl.tw1[hi];
+        twiddle_brev<16, false>(x0, w);
+        twiddle_brev<16, false>(x1, w);
+    }
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap)   // LDS row (a'*16 + b), 16-byte slot cp
+        lds4[(ap * 16 + hi) * 16 + cp] = make_float4(x0[brev<16>(ap)].x, x0[brev<16>(ap)].y,
+                                                     x1[brev<16>(ap)].x, x1[brev<16>(ap)].y);
+    __syncthreads();
+    // pass 2 ownership: a' = hi, columns 2cp, 2cp+1, b = 0..15
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const float4 v = lds4[(hi * 16 + b) * 16 + cp];
+        x0[b] = make_float2(v.x, v.y);
+        x1[b] = make_float2(v.z, v.w);
+    }
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    // k1 = a' + 16*b';  W_N^(n2*k1) = W_N^(n2*a') * (W_N^(16*n2))^b'
+    const unsigned maskN = (unsigned)(N - 1);
+    {
+        const unsigned n2 = (unsigned)col;
+        const float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
+        const float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
+        const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
+        const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
+        x0[0] = cmul(x0[0], base0);
+        x1[0] = cmul(x1[0], base1);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) {
+            x0[brev<16>(e)] = cmul(x0[brev<16>(e)], base0);
+            x1[brev<16>(e)] = cmul(x1[brev<16>(e)], base1);
+        }
+        twiddle_brev<16, false>(x0, step0);
+        twiddle_brev<16, false>(x1, step1);
+    }
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) {
+        const size_t k1 = (size_t)(hi + 16 * bp);
+        out4[k1 * (kN2 / 2)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
+                                           x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
+    }
+}
+
+// K2: one 8192-point row: forward FFT (16 x 16 x 32), multiply by conj(H)/N,
+// inverse FFT.  SPECTRUM = true stores conj(FFT)/N of the needle instead
+// (fft_b, the conj of pairwise_mult_in_place and the 1/len of
+// audio_matcher.rs:430-442 folded into one table).
+template <bool SPECTRUM>
+__global__ void __launch_bounds__(256, 2)
+k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl,
+            unsigned npairs) {
+    extern __shared__ float4 lds4[];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never
+    // correctness): give every XCD whole rows, so that the needle-spectrum row
+    // shared by all pairs is fetched into that XCD's L2 once.
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned row = (seq / npairs) * 8u + xcd, slot = seq % npairs;
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
+    const size_t hoff4 = (size_t)row * (kN2 / 2);
+    const unsigned voff = (unsigned)t * 16u;
+    float2 x0[16], x1[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
+        const float4 v = buf_load4(rrow, voff, a * 4096);
+        x0[a] = make_float2(v.x, v.y);
+        x1[a] = make_float2(v.z, v.w);
+    }
+    // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1 ----
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    const float2 wj0 = pl.tw2[2 * t], wj1 = pl.tw2[2 * t + 1];
+    twiddle_brev<16, false>(x0, wj0);
+    twiddle_brev<16, false>(x1, wj1);
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap)   // L1[a'][j]
+        lds4[ap * 256 + t] = make_float4(x0[brev<16>(ap)].x, x0[brev<16>(ap)].y,
+                                         x1[brev<16>(ap)].x, x1[brev<16>(ap)].y);
+    __syncthreads();
+    // ---- pass 2 over b (stride 32): a' = hi, c = 2cp, 2cp+1; twiddle W_512^(c*b') ----
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const float4 v = lds4[hi * 256 + b * 16 + cp];
+        x0[b] = make_float2(v.x, v.y);
+        x1[b] = make_float2(v.z, v.w);
+    }
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    const float2 wc0 = pl.tw2[32 * cp], wc1 = pl.tw2[32 * cp + 16];
+    twiddle_brev<16, false>(x0, wc0);
+    twiddle_brev<16, false>(x1, wc1);
+    __syncthreads();
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp)   // L2 row u = a'*16 + b', slot cp ^ b'
+        lds4[(hi * 16 + bp) * 16 + (cp ^ bp)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
+                                                            x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
+    __syncthreads();
+    // ---- pass 3 over c (32 contiguous): thread owns row u = t ----
+    float2 z[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 v = lds4[t * 16 + (i ^ cp)];
+        z[2 * i] = make_float2(v.x, v.y);
+        z[2 * i + 1] = make_float2(v.z, v.w);
+    }
+    dif<32, false>(z);
+    if (SPECTRUM) {
+        const float invN = 1.0f / (float)(1u << pl.logN);
+        const __amdgpu_buffer_rsrc_t rho = make_rsrc(reinterpret_cast<float4*>(hc_out) + hoff4, kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            buf_store4(rho, voff, i * 4096, make_float4(z[2 * i].x * invN, -z[2 * i].y * invN,
+                                                       z[2 * i + 1].x * invN, -z[2 * i + 1].y * invN));
+        return;
+    }
+    // ---- pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438) ----
+    __builtin_amdgcn_sched_barrier(0);
+    float4 h[16];
+    {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + hoff4, kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, voff, i * 4096);
+    }
+    float2 q[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float2 m0 = cmul(z[2 * i], make_float2(h[i].x, h[i].y));
+        const float2 m1 = cmul(z[2 * i + 1], make_float2(h[i].z, h[i].w));
+        // z[r] holds frequency brev(r): hand the inverse its input in natural order
+        q[brev<32>(2 * i)] = m0;
+        q[brev<32>(2 * i + 1)] = m1;
+    }
+    // ---- inverse pass 3 over c' ----
+    dif<32, true>(q);   // time index c at q[brev(c)]
+#pragma unroll
+    for (int i = 0; i < 16; ++i)   // own row again, no barrier needed before
+        lds4[t * 16 + (i ^ cp)] = make_float4(q[brev<32>(2 * i)].x, q[brev<32>(2 * i)].y,
+                                              q[brev<32>(2 * i + 1)].x, q[brev<32>(2 * i + 1)].y);
+    __syncthreads();
+    // ---- inverse pass 2 over b': conj twiddle first, then butterflies ----
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) {
+        const float4 v = lds4[(hi * 16 + bp) * 16 + (cp ^ bp)];
+        x0[bp] = make_float2(v.x, v.y);
+        x1[bp] = make_float2(v.z, v.w);
+    }
+    twiddle_nat<16, true>(x0, wc0);
+    twiddle_nat<16, true>(x1, wc1);
+    dif<16, true>(x0);
+    dif<16, true>(x1);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        lds4[hi * 256 + b * 16 + cp] = make_float4(x0[brev<16>(b)].x, x0[brev<16>(b)].y,
+                                                   x1[brev<16>(b)].x, x1[brev<16>(b)].y);
+    __syncthreads();
+    // ---- inverse pass 1 over a' ----
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) {
+        const float4 v = lds4[ap * 256 + t];
+        x0[ap] = make_float2(v.x, v.y);
+        x1[ap] = make_float2(v.z, v.w);
+    }
+    twiddle_nat<16, true>(x0, wj0);
+    twiddle_nat<16, true>(x1, wj1);
+    dif<16, true>(x0);
+    dif<16, true>(x1);
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+        buf_store4(rrow, voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+                                                     x1[brev<16>(a)].x, x1[brev<16>(a)].y));
+}
+
+__device__ __forceinline__ float group16_min(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
+// audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
+// (centered(), :460-464) and the per-32-score (min,max) summary.
+__global__ void __launch_bounds__(256, 2)
+k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, float2* __restrict__ stats32) {
+    extern __shared__ float4 lds4[];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    // XCD-aware placement (speed only): the 16 adjacent column tiles that share
+    // one 128-byte line of stats32 run on the same XCD, so the line is merged in
+    // that L2 before it is written back.  256 tiles per pair = 8 XCDs x 2 x 16.
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
+    const int n2_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
+    const int pair = job.first_pair + (int)slot;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const long long N = 1ll << pl.logN;
+    const long long col = n2_0 + 2 * cp;
+    float2 x0[16], x1[16];
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
+        const float4 v = in4[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+        x0[bp] = make_float2(v.x, v.y);
+        x1[bp] = make_float2(v.z, v.w);
+    }
+    const unsigned maskN = (unsigned)(N - 1);
+    {
+        const unsigned n2 = (unsigned)col;
+        float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
+        float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
+        const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
+        const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            x0[e] = cmulc(x0[e], base0);
+            x1[e] = cmulc(x1[e], base1);
+        }
+        twiddle_nat<16, true>(x0, step0);
+        twiddle_nat<16, true>(x1, step1);
+    }
+    dif<16, true>(x0);   // b at x[brev(b)]
+    dif<16, true>(x1);
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        lds4[(hi * 16 + b) * 16 + cp] = make_float4(x0[brev<16>(b)].x, x0[brev<16>(b)].y,
+                                                    x1[brev<16>(b)].x, x1[brev<16>(b)].y);
+    __syncthreads();
+    // ownership: b = hi, a' = 0..15
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) {
+        const float4 v = lds4[(ap * 16 + hi) * 16 + cp];
+        x0[ap] = make_float2(v.x, v.y);
+        x1[ap] = make_float2(v.z, v.w);
+    }
+    {
+        const float2 w = pl.tw1[hi];
+        twiddle_nat<16, true>(x0, w);
+        twiddle_nat<16, true>(x1, w);
+    }
+    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
+    dif<16, true>(x1);
+    const long long outA = blkA * job.hop, outB = blkB * job.hop;
+    const bool dst8 = ((reinterpret_cast<uintptr_t>(job.dst) & 7) == 0) && ((job.hop & 1) == 0);
+    long long limA = job.out_count - outA; if (limA > job.hop) limA = job.hop;
+    long long limB = blkB < job.nblocks ? job.out_count - outB : 0; if (limB > job.hop) limB = job.hop;
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const long long n = (long long)(a * 16 + hi) * kN2 + col;
+        const float2 v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
+        const float a0 = v0.x * out_scale, a1 = v1.x * out_scale;   // block A: columns col, col+1
+        const float b0 = v0.y * out_scale, b1 = v1.y * out_scale;   // block B
+        // hop and out offsets are even whenever this kernel is used, so a pair is
+        // valid or invalid as a whole except at the very end of the score array
+        if (dst8) {
+            if (n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(a0, a1);
+            else if (n < limA) job.dst[outA + n] = a0;
+            if (n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(b0, b1);
+            else if (n < limB) job.dst[outB + n] = b0;
+        } else {
+            if (n < limA) job.dst[outA + n] = a0;
+            if (n + 1 < limA) job.dst[outA + n + 1] = a1;
+            if (n < limB) job.dst[outB + n] = b0;
+            if (n + 1 < limB) job.dst[outB + n + 1] = b1;
+        }
+        // (min,max) of the 32 consecutive scores held by the 16 lanes of this row
+        const long long run = (long long)(a * 16 + hi) * kN2 + n2_0;
+        if (stats32 == nullptr) continue;
+        if (run < limA) {   // uniform over the 16-lane group
+            float mn = fminf(n < limA ? a0 : FLT_MAX, n + 1 < limA ? a1 : FLT_MAX);
+            float mx = fmaxf(n < limA ? a0 : -FLT_MAX, n + 1 < limA ? a1 : -FLT_MAX);
+            mn = group16_min(mn); mx = group16_max(mx);
+            if (cp == 0) stats32[(outA + run) >> 5] = make_float2(mn, mx);
+        }
+        if (run < limB) {
+            float mn = fminf(n < limB ? b0 : FLT_MAX, n + 1 < limB ? b1 : FLT_MAX);
+            float mx = fmaxf(n < limB ? b0 : -FLT_MAX, n + 1 < limB ? b1 : -FLT_MAX);
+            mn = group16_min(mn); mx = group16_max(mx);
+            if (cp == 0) stats32[(outB + run) >> 5] = make_float2(mn, mx);
+        }
+    }
+}
+
+// ===========================================================================
+// Generic kernels: any N1 x N2, transforms done by in-LDS radix-4 passes.
+// ===========================================================================
 // Forward DIF transform of length 2^logL along the slow axis of
 // s[i * 2^BL + c] (2^BL independent columns c).  tw[k] = W_L^k, k < L/2.
 // Each radix-4 step is two fused radix-2 DIF stages, so the result is in
@@ -138,11 +593,10 @@ __device__ __forceinline__ float load_padded(const float* __restrict__ src, long
     return (i >= 0 && i < len) ? src[i] : 0.0f;
 }
 
-// ---------------------------------------------------------------------------
-// K1: PCM/f32 window load (pad(), audio_matcher.rs:232-235, 422) + column FFTs.
+// K1 generic: row p of the work matrix holds frequency k1 = bitrev(p).
 template <int BL>
 __global__ void __launch_bounds__(kFftThreads)
-k1_cols_fwd(Job job, float2* __restrict__ work, PlanDev pl) {
+k1_cols_fwd_gen(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float2 s[];
     const int N1 = 1 << pl.logN1, N2 = 1 << pl.logN2;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -163,31 +617,24 @@ k1_cols_fwd(Job job, float2* __restrict__ work, PlanDev pl) {
     __syncthreads();
     lds_fft_fwd<BL>(s, pl.logN1, pl.tw1, tid, nthr);
     float2* out = work + ((size_t)blockIdx.y << pl.logN) + n2_0;
+    const unsigned maskN = (1u << pl.logN) - 1u;
     for (int idx = tid; idx < total; idx += nthr) {
         const int p = idx >> BL, c = idx & ((1 << BL) - 1);
-        out[(size_t)p * N2 + c] = s[idx];
+        const unsigned k1 = __brev((unsigned)p) >> (32 - pl.logN1);
+        const float2 w = tw_big(pl, ((unsigned)(n2_0 + c) * k1) & maskN);
+        out[(size_t)p * N2 + c] = cmul(s[idx], w);
     }
 }
 
-// ---------------------------------------------------------------------------
-// K2: one row.  SPECTRUM = true writes conj(FFT)/N of the needle block instead
-// of correlating (fft_b + the conj of pairwise_mult_in_place + the 1/len of
-// audio_matcher.rs:430-442 folded into one table).
 template <bool SPECTRUM>
 __global__ void __launch_bounds__(kFftThreads)
-k2_rows(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl) {
+k2_rows_gen(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl) {
     extern __shared__ float2 s[];
     const int N2 = 1 << pl.logN2;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int p = blockIdx.x;
-    const unsigned k1 = pl.logN1 ? (__brev((unsigned)p) >> (32 - pl.logN1)) : 0u;
     float2* row = work + ((size_t)blockIdx.y << pl.logN) + (size_t)p * N2;
-    const unsigned maskN = (1u << pl.logN) - 1u, maskLo = (1u << pl.logLo) - 1u;
-    for (int n2 = tid; n2 < N2; n2 += nthr) {
-        const unsigned m = ((unsigned)n2 * k1) & maskN;
-        const float2 w = cmul(pl.twhi[m >> pl.logLo], pl.twlo[m & maskLo]);
-        s[n2] = cmul(row[n2], w);
-    }
+    for (int n2 = tid; n2 < N2; n2 += nthr) s[n2] = row[n2];
     __syncthreads();
     lds_fft_fwd<0>(s, pl.logN2, pl.tw2, tid, nthr);
     const size_t hoff = (size_t)p * N2;
@@ -202,19 +649,12 @@ k2_rows(float2* __restrict__ work, const float2* __restrict__ hc, float2* __rest
     for (int q = tid; q < N2; q += nthr) s[q] = cmul(s[q], hc[hoff + q]);
     __syncthreads();
     lds_fft_inv<0>(s, pl.logN2, pl.tw2, tid, nthr);
-    for (int n2 = tid; n2 < N2; n2 += nthr) {
-        const unsigned m = ((unsigned)n2 * k1) & maskN;
-        const float2 w = cmul(pl.twhi[m >> pl.logLo], pl.twlo[m & maskLo]);
-        row[n2] = cmulc(s[n2], w);
-    }
+    for (int n2 = tid; n2 < N2; n2 += nthr) row[n2] = s[n2];
 }
 
-// ---------------------------------------------------------------------------
-// K3: inverse column FFTs, scaling (scale_slice, audio_matcher.rs:246-252,
-// 306-308) and the crop to the block's valid lags (centered(), :460-464).
 template <int BL>
 __global__ void __launch_bounds__(kFftThreads)
-k3_cols_inv(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale) {
+k3_cols_inv_gen(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale) {
     extern __shared__ float2 s[];
     const int N1 = 1 << pl.logN1, N2 = 1 << pl.logN2;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -224,9 +664,12 @@ k3_cols_inv(Job job, const float2* __restrict__ work, PlanDev pl, float out_scal
     const bool validB = blkB < job.nblocks;
     const int total = N1 << BL;
     const float2* in = work + ((size_t)blockIdx.y << pl.logN) + n2_0;
+    const unsigned maskN = (1u << pl.logN) - 1u;
     for (int idx = tid; idx < total; idx += nthr) {
         const int p = idx >> BL, c = idx & ((1 << BL) - 1);
-        s[idx] = in[(size_t)p * N2 + c];
+        const unsigned k1 = __brev((unsigned)p) >> (32 - pl.logN1);
+        const float2 w = tw_big(pl, ((unsigned)(n2_0 + c) * k1) & maskN);
+        s[idx] = cmulc(in[(size_t)p * N2 + c], w);
     }
     __syncthreads();
     lds_fft_inv<BL>(s, pl.logN1, pl.tw1, tid, nthr);
@@ -243,45 +686,73 @@ k3_cols_inv(Job job, const float2* __restrict__ work, PlanDev pl, float out_scal
 
 // ---------------------------------------------------------------------------
 static constexpr int kMaxLds = 160 * 1024;
+static constexpr int kR16Lds = 64 * 1024;
+
+bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
 
 hipError_t fft_kernels_init() {
     hipError_t e;
-    e = hipFuncSetAttribute((const void*)k1_cols_fwd<kColsLog>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+#define AM_SET_LDS(fn, bytes)                                                                     \
+    e = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k3_cols_inv<kColsLog>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k2_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k2_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-    return e;
+    AM_SET_LDS(k1_cols_fwd_gen<kColsLog>, kMaxLds)
+    AM_SET_LDS(k3_cols_inv_gen<kColsLog>, kMaxLds)
+    AM_SET_LDS(k2_rows_gen<false>, kMaxLds)
+    AM_SET_LDS(k2_rows_gen<true>, kMaxLds)
+    AM_SET_LDS(k1_cols_fwd_r16, kR16Lds)
+    AM_SET_LDS(k3_cols_inv_r16, kR16Lds)
+    AM_SET_LDS(k2_rows_r16<false>, kR16Lds)
+    AM_SET_LDS(k2_rows_r16<true>, kR16Lds)
+#undef AM_SET_LDS
+    return hipSuccess;
 }
 
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
-    const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
-    hipLaunchKernelGGL(k1_cols_fwd<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl);
+    if (plan_is_r16(pl)) {
+        hipLaunchKernelGGL(k1_cols_fwd_r16, grid, dim3(256), kR16Lds, st, job, work, pl);
+    } else {
+        const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
+        hipLaunchKernelGGL(k1_cols_fwd_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, npairs);
-    const size_t lds = sizeof(float2) << pl.logN2;
-    hipLaunchKernelGGL(k2_rows<false>, grid, dim3(kFftThreads), lds, st, work, hc, (float2*)nullptr, pl);
+    if (plan_is_r16(pl)) {
+        hipLaunchKernelGGL(k2_rows_r16<false>, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+                           (float2*)nullptr, pl, (unsigned)npairs);
+    } else {
+        const size_t lds = sizeof(float2) << pl.logN2;
+        hipLaunchKernelGGL(k2_rows_gen<false>, grid, dim3(kFftThreads), lds, st, work, hc, (float2*)nullptr, pl);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, 1);
-    const size_t lds = sizeof(float2) << pl.logN2;
-    hipLaunchKernelGGL(k2_rows<true>, grid, dim3(kFftThreads), lds, st, work, (const float2*)nullptr, hc_out, pl);
+    if (plan_is_r16(pl)) {
+        hipLaunchKernelGGL(k2_rows_r16<true>, dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
+                           hc_out, pl, 1u);
+    } else {
+        const size_t lds = sizeof(float2) << pl.logN2;
+        hipLaunchKernelGGL(k2_rows_gen<true>, grid, dim3(kFftThreads), lds, st, work, (const float2*)nullptr, hc_out, pl);
+    }
     return hipGetLastError();
 }
 
+// stats32 != nullptr only for the r16 plan with an even, 32-aligned hop
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale) {
+                     const PlanDev& pl, float out_scale, float2* stats32) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
-    const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
-    hipLaunchKernelGGL(k3_cols_inv<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl, out_scale);
+    if (plan_is_r16(pl)) {
+        hipLaunchKernelGGL(k3_cols_inv_r16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16Lds, st, job, work,
+                           pl, out_scale, stats32);
+    } else {
+        const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
+        hipLaunchKernelGGL(k3_cols_inv_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl, out_scale);
+    }
     return hipGetLastError();
 }
 

@@ -47,14 +47,25 @@ struct Segment {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl);
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
+// stats32 (optional, r16 plan only): (min,max) per 32 consecutive scores
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale);
+                     const PlanDev& pl, float out_scale, float2* stats32);
+bool plan_is_r16(const PlanDev& pl);
 hipError_t fft_kernels_init();
 
 hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats);
+hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats);
+// per-chunk result header: the count, an overflow flag and the first few peaks
+// inline, so that the common case needs a single small device-to-host copy
+constexpr int kInlinePeaks = 4;
+struct SegHeader {
+    int n;
+    int overflow;
+    am_peak first[kInlinePeaks];
+};
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, int* d_out_n, int* d_err);
+                        am_peak* d_out, SegHeader* d_hdr);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_out);
 hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
                         long long n, float amp);

@@ -29,6 +29,7 @@ namespace am {
 constexpr int kPeakThreads = 256;
 constexpr int kWaves = kPeakThreads / 64;
 constexpr int kQueueCap = kTile;  // local maxima of one tile (<= kTile/2, head/tail pieces < kTile)
+constexpr int kCandCap = 1024;    // candidate tiles listed per chunk before falling back to all tiles
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -58,6 +59,20 @@ __global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, l
         for (int k = 1; k < 4; ++k) { mn = fminf(mn, smin[k]); mx = fmaxf(mx, smax[k]); }
         stats[blockIdx.x] = make_float2(fminf(mn, smin[0]), fmaxf(mx, smax[0]));
     }
+}
+
+// level-1 summary (1024 scores) from K3's level-0 summary (32 scores): one
+// 32-lane half wave per tile
+__global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s32, long long n32,
+                                                    float2* __restrict__ stats, long long ntiles) {
+    const long long tile = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    const long long idx = tile * 32 + l;
+    if (tile < ntiles && idx < n32) { const float2 v = s32[idx]; mn = v.x; mx = v.y; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if (l == 0 && tile < ntiles) stats[tile] = make_float2(mn, mx);
 }
 
 // ---------------------------------------------------------------------------
@@ -155,7 +170,7 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
-             am_peak* __restrict__ out, int* __restrict__ out_n, int* __restrict__ err) {
+             am_peak* __restrict__ out, SegHeader* __restrict__ hdr) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -164,14 +179,16 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ int res_n;
     __shared__ int order[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int overflow;
+    __shared__ int cand_tiles[kCandCap];
+    __shared__ int cand_n;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Segment sg = segs[blockIdx.x];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
-    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; }
+    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; }
     if (b - a < 3) {
-        if (tid == 0) out_n[blockIdx.x] = 0;
+        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; }
         return;
     }
     // full tiles [tf, tl) lie completely inside [a, b)
@@ -193,18 +210,30 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __syncthreads();
     const float seg_min = seg_min_s;
 
-    // ---- pieces: head, full tiles, tail ------------------------------------
-    const long long npieces = (has_full ? (tl - tf) : 0) + 2;
+    // ---- candidate tiles: prominence <= height - chunk_min (monotone f32
+    // rounding), so a tile whose maximum fails the test cannot hold a peak ----
+    if (has_full) {
+        for (long long t = tf + tid; t < tl; t += kPeakThreads) {
+            if ((stats[t].y - seg_min) >= min_prom) {
+                const int slot = atomicAdd(&cand_n, 1);
+                if (slot < kCandCap) cand_tiles[slot] = (int)(t - tf);
+            }
+        }
+    }
+    __syncthreads();
+    // more candidates than the list holds: visit every full tile instead
+    const bool all_tiles = cand_n > kCandCap;
+    const long long nmid = has_full ? (all_tiles ? (tl - tf) : cand_n) : 0;
+    // ---- pieces: head, candidate tiles, tail --------------------------------
+    const long long npieces = nmid + 2;
     for (long long pc = 0; pc < npieces; ++pc) {
         long long lo, hi;
         if (pc == 0) { lo = a; hi = head_hi; }
         else if (pc == npieces - 1) { lo = tail_lo; hi = b; }
         else {
-            const long long t = tf + (pc - 1);
+            const long long t = tf + (all_tiles ? (pc - 1) : (long long)cand_tiles[pc - 1]);
             lo = t * kTile; hi = lo + kTile;
-            // prominence <= height - chunk_min (monotone f32 rounding), so a tile
-            // whose maximum fails the test cannot hold a qualifying peak
-            if (!((stats[t].y - seg_min) >= min_prom)) continue;
+            if (all_tiles && !((stats[t].y - seg_min) >= min_prom)) continue;
         }
         if (hi <= lo) continue;
         // -- local maxima with flat tops whose height can qualify --
@@ -266,10 +295,13 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
                     if (d < min_dist) ok = false;
                 }
             }
-            if (ok) my_out[kept++] = pk;
+            if (ok) {
+                if (kept < kInlinePeaks) hdr[blockIdx.x].first[kept] = pk;
+                my_out[kept++] = pk;
+            }
         }
-        out_n[blockIdx.x] = kept;
-        if (overflow) atomicExch(err, 1);
+        hdr[blockIdx.x].n = kept;
+        hdr[blockIdx.x].overflow = overflow;
     }
 }
 
@@ -338,12 +370,21 @@ hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2
     return hipGetLastError();
 }
 
+hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats) {
+    const long long n32 = (n + 31) / 32;
+    const long long tiles = (n + kTile - 1) / kTile;
+    if (tiles <= 0) return hipSuccess;
+    const long long blocks = (tiles * 32 + 255) / 256;
+    hipLaunchKernelGGL(stats_reduce, dim3((unsigned)blocks), dim3(256), 0, st, stats32, n32, stats, tiles);
+    return hipGetLastError();
+}
+
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, int* d_out_n, int* d_err) {
+                        am_peak* d_out, SegHeader* d_hdr) {
     if (nsegs <= 0) return hipSuccess;
     hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_out_n, d_err);
+                       min_prom, min_dist, d_out, d_hdr);
     return hipGetLastError();
 }
 
