@@ -10,6 +10,7 @@
 // All arithmetic on samples runs in the HIP kernels of am_fft.hip /
 // am_peaks.hip; there is no CPU fallback.
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -93,7 +94,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, scores, stats, stats32, segs, hdr, peaks, counts, io_in, io_out, sum;
+    DevBuf work, scores, stats, stats32, wflags, segs, hdr, peaks, counts, io_in, io_out, sum;
     HostBuf pinned;
     // profiling
     bool prof = false;
@@ -202,6 +203,10 @@ struct am_needle {
     size_t n = 0;
     float inv_autocorr = 0.f;
     std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
+    // lowest chunk minimum of the scaled scores seen so far (per scale mode);
+    // drives the raw-score write threshold of the fused scan
+    bool have_min[2] = {false, false};
+    float min_seg_min[2] = {0.f, 0.f};
 };
 
 namespace am {
@@ -258,9 +263,15 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
 // The overlap-save engine: scores[j] = factor * sum_n X[j + n - lead] needle[n]
 // When want_stats is set and the plan supports it, K3 also writes the level-0
 // (min,max) summary into c->stats32 and *have_stats becomes true.
+struct ScanRequest {
+    float theta;             // in: raw-score write threshold
+    long long seg_c, seg_d;  // in: chunk geometry (scores i*seg_c .. i*seg_c + seg_d)
+    bool fused;              // out: K3 produced stats32 / wflags
+    SparseScores sparse;     // out: description of what was written
+};
 static int run_correlation(am_needle* h, const float* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
-                           bool want_stats = false, bool* have_stats = nullptr) {
+                           ScanRequest* scan_req = nullptr) {
     Ctx* c = h->ctx;
     int logN = 0;
     int rc = pick_log_n(h->n, out_count, &logN);
@@ -277,12 +288,21 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
     long long ppg = std::max<long long>(1, g_opt_pairs_per_group);
     if (ppg > npairs) ppg = npairs;
     if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
-    float2* stats32 = nullptr;
-    if (have_stats) *have_stats = false;
-    if (want_stats && plan_is_r16(pl->dev) && (hop % kTile) == 0) {
-        if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-        stats32 = (float2*)c->stats32.p;
-        if (have_stats) *have_stats = true;
+    ScanCfg scan{};
+    if (scan_req) {
+        scan_req->fused = false;
+        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2};
+        if (plan_is_r16(pl->dev) && (hop % kTile) == 0) {
+            if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
+            if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
+            scan.stats32 = (float2*)c->stats32.p;
+            scan.wflags = (unsigned char*)c->wflags.p;
+            scan.theta = scan_req->theta;
+            scan.seg_c = scan_req->seg_c;
+            scan.seg_d = scan_req->seg_d;
+            scan_req->fused = true;
+            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2};
+        }
     }
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead;
@@ -292,7 +312,7 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
         job.first_pair = (int)first;
         { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev)); }
         { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev)); }
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, factor, stats32)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, factor, scan)); }
     }
     return AM_OK;
 }
@@ -342,7 +362,9 @@ static bool is_overshadowed(const am_peak& element, const am_peak* other, uint32
 // resident score array; segment descriptors and result headers live at
 // [seg_off, seg_off + nsegs) of the context's segment / header buffers.
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
-                       float min_prom, long long min_dist, const float2* d_stats32) {
+                       float min_prom, long long min_dist, const ScanRequest* scan) {
+    const float2* d_stats32 = (scan && scan->fused) ? scan->sparse.stats32 : nullptr;
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5};
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;
@@ -356,7 +378,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         ProfScope ps(c, KN_PEAKS);
         AM_HIP(launch_peaks(c->stream, d_scores, n_scores, (const float2*)c->stats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p + seg_off));
+                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p + seg_off, sp));
     }
     return AM_OK;
 }
@@ -404,6 +426,15 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
     if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
         return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB (AM_SCALE_MY depends on the window length)");
     const float factor = scale_factor(h, p->scale, 1);
+    // Raw scores are written only where some score >= theta.  theta sits half a
+    // prominence above the lowest chunk minimum seen with this needle; the first
+    // call (no history) writes everything.  The peak kernel certifies per chunk
+    // that theta was low enough; a failed certificate redoes that haystack.
+    const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
+    ScanRequest scan{};
+    scan.theta = (h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+    scan.seg_c = (long long)p->chunk;
+    scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
     std::vector<Segment> segs;
     std::vector<int> seg_off(n_hay + 1, 0);
     size_t max_scores = 0, max_segs = 0;
@@ -433,11 +464,10 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
-        bool have_stats = false;
         if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
-                                  true, &have_stats))) return rc;
+                                  &scan))) return rc;
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, seg_off[k], ns, p->min_prominence,
-                              (long long)p->min_distance, have_stats ? (const float2*)c->stats32.p : nullptr))) return rc;
+                              (long long)p->min_distance, &scan))) return rc;
     }
     AM_HIP(hipMemcpyAsync(h_hdr, c->hdr.p, hdr_bytes, hipMemcpyDeviceToHost, c->stream));
     AM_HIP(hipStreamSynchronize(c->stream));
@@ -448,8 +478,9 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
         if (s1 == s0) continue;
         bool big = false;
         for (int i = s0; i < s1; ++i) {
-            if (h_hdr[i].overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-            if (h_hdr[i].n > kInlinePeaks) big = true;
+            if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+            if (h_hdr[i].n > kInlinePeaks || (h_hdr[i].overflow & 2)) big = true;
+            if (!h->have_min[sm] || h_hdr[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = h_hdr[i].seg_min; h->have_min[sm] = true; }
         }
         all.clear();
         if (!big) {
@@ -457,16 +488,21 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
             for (int i = s0; i < s1; ++i)
                 for (int j = 0; j < h_hdr[i].n; ++j) all.push_back(h_hdr[i].first[j]);
         } else {
-            // rare: a chunk with more peaks than a header holds; its full list was
-            // overwritten by later haystacks, so redo this haystack on its own
+            // rare: a chunk with more peaks than a header holds (its full list was
+            // overwritten by later haystacks) or a chunk whose minimum was below
+            // what theta assumed: redo this haystack on its own, writing every score
             const long long out_count = (long long)(lens[k] - s + 1);
-            bool have_stats = false;
+            ScanRequest full = scan;
+            full.theta = -FLT_MAX;
             if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
-                                      true, &have_stats))) return rc;
+                                      &full))) return rc;
             if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, s0, s1 - s0, p->min_prominence,
-                                  (long long)p->min_distance, have_stats ? (const float2*)c->stats32.p : nullptr))) return rc;
+                                  (long long)p->min_distance, &full))) return rc;
+            AM_HIP(hipMemcpyAsync(h_hdr + s0, (SegHeader*)c->hdr.p + s0, sizeof(SegHeader) * (s1 - s0),
+                                  hipMemcpyDeviceToHost, c->stream));
             AM_HIP(hipStreamSynchronize(c->stream));
             for (int i = s0; i < s1; ++i) {
+                if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
                 const int cnt = h_hdr[i].n;
                 if (cnt <= 0) continue;
                 const size_t old = all.size();

@@ -379,6 +379,49 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
                                                      x1[brev<16>(a)].x, x1[brev<16>(a)].y));
 }
 
+// Reduction across the 16 lanes of a group of 16 per-lane values v[0..15]
+// (lane cp ends up with the reduction of v[cp]): log-step exchange in which
+// every step halves the rows a lane still carries.
+template <bool MAX>
+__device__ __forceinline__ float treduce16(const float (&v)[16], int cp) {
+    float w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const float send = (cp & 8) ? v[a] : v[a + 8], keep = (cp & 8) ? v[a + 8] : v[a];
+        const float r = __shfl_xor(send, 8);
+        w8[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float send = (cp & 4) ? w8[a] : w8[a + 4], keep = (cp & 4) ? w8[a + 4] : w8[a];
+        const float r = __shfl_xor(send, 4);
+        w4[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float send = (cp & 2) ? w4[a] : w4[a + 2], keep = (cp & 2) ? w4[a + 2] : w4[a];
+        const float r = __shfl_xor(send, 2);
+        w2[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
+    }
+    const float send = (cp & 1) ? w2[0] : w2[1], keep = (cp & 1) ? w2[1] : w2[0];
+    const float r = __shfl_xor(send, 1);
+    return MAX ? fmaxf(keep, r) : fminf(keep, r);
+}
+
+// Does the 32-score run [lo, lo+32) hold the first (i*c) or the last
+// (i*c + d) score of a reference chunk?  (audio_matcher.rs:104, 119: chunk i
+// covers scores [i*c, i*c + d].)  Such runs are only partly inside a chunk, so
+// the peak pick needs their raw scores, not just their summary.
+__device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, long long d) {
+    if (c <= 0) return true;
+    const long long q0 = (lo + 31) / c;
+    if (q0 * c >= lo) return true;
+    const long long lo2 = lo - d;
+    if (lo2 + 31 < 0) return false;
+    const long long q1 = (lo2 + 31) / c;
+    return q1 * c >= lo2;
+}
+
 __device__ __forceinline__ float group16_min(float v) {
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -394,7 +437,7 @@ __device__ __forceinline__ float group16_max(float v) {
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
 __global__ void __launch_bounds__(256, 2)
-k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, float2* __restrict__ stats32) {
+k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
@@ -456,39 +499,71 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     const bool dst8 = ((reinterpret_cast<uintptr_t>(job.dst) & 7) == 0) && ((job.hop & 1) == 0);
     long long limA = job.out_count - outA; if (limA > job.hop) limA = job.hop;
     long long limB = blkB < job.nblocks ? job.out_count - outB : 0; if (limB > job.hop) limB = job.hop;
+    // scores of row n1 = a*16 + hi: block A columns col, col+1 = (sa0, sa1), block B = (sb0, sb1)
+    float sa0[16], sa1[16], sb0[16], sb1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        const long long n = (long long)(a * 16 + hi) * kN2 + col;
         const float2 v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
-        const float a0 = v0.x * out_scale, a1 = v1.x * out_scale;   // block A: columns col, col+1
-        const float b0 = v0.y * out_scale, b1 = v1.y * out_scale;   // block B
-        // hop and out offsets are even whenever this kernel is used, so a pair is
-        // valid or invalid as a whole except at the very end of the score array
-        if (dst8) {
-            if (n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(a0, a1);
-            else if (n < limA) job.dst[outA + n] = a0;
-            if (n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(b0, b1);
-            else if (n < limB) job.dst[outB + n] = b0;
-        } else {
-            if (n < limA) job.dst[outA + n] = a0;
-            if (n + 1 < limA) job.dst[outA + n + 1] = a1;
-            if (n < limB) job.dst[outB + n] = b0;
-            if (n + 1 < limB) job.dst[outB + n + 1] = b1;
+        sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
+        sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
+    }
+    bool wantA = true, wantB = true;
+    if (scan.stats32 != nullptr) {
+        // ---- fused score scan: (min,max) per 32 consecutive scores ------------
+        float mnA[16], mxA[16], mnB[16], mxB[16];
+        float tmaxA = -FLT_MAX, tmaxB = -FLT_MAX;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            const bool a0v = n < limA, a1v = n + 1 < limA, b0v = n < limB, b1v = n + 1 < limB;
+            mnA[a] = fminf(a0v ? sa0[a] : FLT_MAX, a1v ? sa1[a] : FLT_MAX);
+            mxA[a] = fmaxf(a0v ? sa0[a] : -FLT_MAX, a1v ? sa1[a] : -FLT_MAX);
+            mnB[a] = fminf(b0v ? sb0[a] : FLT_MAX, b1v ? sb1[a] : FLT_MAX);
+            mxB[a] = fmaxf(b0v ? sb0[a] : -FLT_MAX, b1v ? sb1[a] : -FLT_MAX);
+            tmaxA = fmaxf(tmaxA, mxA[a]);
+            tmaxB = fmaxf(tmaxB, mxB[a]);
         }
-        // (min,max) of the 32 consecutive scores held by the 16 lanes of this row
-        const long long run = (long long)(a * 16 + hi) * kN2 + n2_0;
-        if (stats32 == nullptr) continue;
-        if (run < limA) {   // uniform over the 16-lane group
-            float mn = fminf(n < limA ? a0 : FLT_MAX, n + 1 < limA ? a1 : FLT_MAX);
-            float mx = fmaxf(n < limA ? a0 : -FLT_MAX, n + 1 < limA ? a1 : -FLT_MAX);
-            mn = group16_min(mn); mx = group16_max(mx);
-            if (cp == 0) stats32[(outA + run) >> 5] = make_float2(mn, mx);
+        // raw scores leave the chip only for tiles that can matter to the peak
+        // pick: some score >= theta, or a run that straddles a chunk edge
+        const long long rowrun = (long long)t * kN2 + n2_0;   // thread t checks row n1 = t
+        const bool edgeA = rowrun < limA && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d);
+        const bool edgeB = rowrun < limB && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d);
+        wantA = __syncthreads_or((tmaxA >= scan.theta) || edgeA) != 0;
+        wantB = __syncthreads_or((tmaxB >= scan.theta) || edgeB) != 0;
+        if (t == 0 && scan.wflags != nullptr) {
+            const unsigned tile = (unsigned)n2_0 >> kColsLog;
+            scan.wflags[blkA * (kN2 >> kColsLog) + tile] = wantA ? 1 : 0;
+            if (blkB < job.nblocks) scan.wflags[blkB * (kN2 >> kColsLog) + tile] = wantB ? 1 : 0;
         }
-        if (run < limB) {
-            float mn = fminf(n < limB ? b0 : FLT_MAX, n + 1 < limB ? b1 : FLT_MAX);
-            float mx = fmaxf(n < limB ? b0 : -FLT_MAX, n + 1 < limB ? b1 : -FLT_MAX);
-            mn = group16_min(mn); mx = group16_max(mx);
-            if (cp == 0) stats32[(outB + run) >> 5] = make_float2(mn, mx);
+        const float rmnA = treduce16<false>(mnA, cp), rmxA = treduce16<true>(mxA, cp);
+        const float rmnB = treduce16<false>(mnB, cp), rmxB = treduce16<true>(mxB, cp);
+        // lane cp now owns the summary of row n1 = cp*16 + hi
+        const long long run = (long long)(cp * 16 + hi) * kN2 + n2_0;
+        if (run < limA) scan.stats32[(outA + run) >> 5] = make_float2(rmnA, rmxA);
+        if (run < limB) scan.stats32[(outB + run) >> 5] = make_float2(rmnB, rmxB);
+    }
+    if (wantA) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            // hop and out offsets are even whenever this kernel is used, so a pair is
+            // valid or invalid as a whole except at the very end of the score array
+            if (dst8 && n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(sa0[a], sa1[a]);
+            else {
+                if (n < limA) job.dst[outA + n] = sa0[a];
+                if (n + 1 < limA) job.dst[outA + n + 1] = sa1[a];
+            }
+        }
+    }
+    if (wantB) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            if (dst8 && n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(sb0[a], sb1[a]);
+            else {
+                if (n < limB) job.dst[outB + n] = sb0[a];
+                if (n + 1 < limB) job.dst[outB + n + 1] = sb1[a];
+            }
         }
     }
 }
@@ -742,13 +817,13 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
     return hipGetLastError();
 }
 
-// stats32 != nullptr only for the r16 plan with an even, 32-aligned hop
+// scan.stats32 != nullptr only for the r16 plan with a 1024-aligned hop
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, float2* stats32) {
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl)) {
         hipLaunchKernelGGL(k3_cols_inv_r16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16Lds, st, job, work,
-                           pl, out_scale, stats32);
+                           pl, out_scale, scan);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
         hipLaunchKernelGGL(k3_cols_inv_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl, out_scale);

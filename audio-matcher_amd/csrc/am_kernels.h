@@ -47,9 +47,16 @@ struct Segment {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl);
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
-// stats32 (optional, r16 plan only): (min,max) per 32 consecutive scores
+// The score scan fused into K3 (r16 plan only).  stats32 == nullptr disables it
+// (plain correlation: every score is written).
+struct ScanCfg {
+    float2* stats32;          // (min,max) per 32 consecutive scores, always written
+    unsigned char* wflags;    // [block][column tile] = 1 when the tile's raw scores were written
+    float theta;              // raw scores are written for tiles with a score >= theta ...
+    long long seg_c, seg_d;   // ... and for runs that hold score i*seg_c or i*seg_c + seg_d (chunk edges)
+};
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, float2* stats32);
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan);
 bool plan_is_r16(const PlanDev& pl);
 hipError_t fft_kernels_init();
 
@@ -60,12 +67,21 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 constexpr int kInlinePeaks = 4;
 struct SegHeader {
     int n;
-    int overflow;
+    int overflow;      // bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks; bit 1: theta too high for this chunk
+    float seg_min;     // (lower bound of the) chunk minimum, for adapting theta
+    int pad_;
     am_peak first[kInlinePeaks];
+};
+// Which raw scores exist (K3 writes them sparsely): wflags == nullptr means all.
+struct SparseScores {
+    const unsigned char* wflags;
+    const float2* stats32;
+    float theta;
+    int hop, log_n2;
 };
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, SegHeader* d_hdr);
+                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_out);
 hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
                         long long n, float amp);

@@ -78,11 +78,31 @@ __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s
 // ---------------------------------------------------------------------------
 struct Cand { long long ps, pe; float h; };
 
+// K3 writes raw scores only for tiles that can matter (am_fft.hip); everywhere
+// else only the per-32 summary exists.
+__device__ __forceinline__ bool run_written(const SparseScores& sp, long long idx) {
+    if (sp.wflags == nullptr) return true;
+    const long long blk = idx / sp.hop;
+    const unsigned n = (unsigned)(idx - blk * sp.hop);
+    const unsigned tile = (n & ((1u << sp.log_n2) - 1u)) >> 5;
+    return sp.wflags[blk * (long long)(1 << (sp.log_n2 - 5)) + tile] != 0;
+}
+// for minima: exact where written, else the run's minimum (exact whenever the
+// whole run lies in the range being reduced, a lower bound otherwise)
+__device__ __forceinline__ float score_for_min(const float* __restrict__ g, const SparseScores& sp, long long idx) {
+    return run_written(sp, idx) ? g[idx] : sp.stats32[idx >> 5].x;
+}
+// for comparisons with a candidate height (>= theta): an unwritten score is < theta
+__device__ __forceinline__ float score_for_cmp(const float* __restrict__ g, const SparseScores& sp, long long idx) {
+    return run_written(sp, idx) ? g[idx] : -FLT_MAX;
+}
+
 // One wave-cooperative step of the walk to the left of `cur` (exclusive) down
 // to `a`: either skips up to 64 whole tiles through their summaries or looks at
 // up to 64 raw samples.  Returns true when a strictly higher sample ended the
 // walk; `cur` reaching `a` ends it at the chunk edge.
 __device__ __forceinline__ bool step_left(const float* __restrict__ g, const float2* __restrict__ stats,
+                                          const SparseScores& sp,
                                           long long a, long long& cur, float h, float& vmin, int lane) {
     if ((cur % kTile) == 0 && cur - kTile >= a) {
         const long long t = cur / kTile - 1 - lane;
@@ -102,7 +122,7 @@ __device__ __forceinline__ bool step_left(const float* __restrict__ g, const flo
     const long long lo = tile_lo > a ? tile_lo : a;
     const long long idx = cur - 1 - lane;
     const bool valid = idx >= lo;
-    const float v = valid ? g[idx] : 0.0f;
+    const float v = valid ? score_for_min(g, sp, idx) : 0.0f;
     const unsigned long long higher = __ballot(valid && v > h);
     const int nval = __popcll(__ballot(valid));
     const int ntake = higher ? (__ffsll((long long)higher) - 1) : nval;
@@ -113,6 +133,7 @@ __device__ __forceinline__ bool step_left(const float* __restrict__ g, const flo
 
 // Mirror image: walk to the right from `cur` (inclusive) up to `b` (exclusive).
 __device__ __forceinline__ bool step_right(const float* __restrict__ g, const float2* __restrict__ stats,
+                                           const SparseScores& sp,
                                            long long b, long long& cur, float h, float& vmin, int lane) {
     if ((cur % kTile) == 0 && cur + kTile <= b) {
         const long long t = cur / kTile + lane;
@@ -132,7 +153,7 @@ __device__ __forceinline__ bool step_right(const float* __restrict__ g, const fl
     const long long hi = tile_hi < b ? tile_hi : b;
     const long long idx = cur + lane;
     const bool valid = idx < hi;
-    const float v = valid ? g[idx] : 0.0f;
+    const float v = valid ? score_for_min(g, sp, idx) : 0.0f;
     const unsigned long long higher = __ballot(valid && v > h);
     const int nval = __popcll(__ballot(valid));
     const int ntake = higher ? (__ffsll((long long)higher) - 1) : nval;
@@ -146,19 +167,19 @@ __device__ __forceinline__ bool step_right(const float* __restrict__ g, const fl
 // peak is rejected after a few samples (prominence <= h - min of a finished
 // side).  Returns false when prominence < min_prom.
 __device__ bool prominence(const float* __restrict__ g, const float2* __restrict__ stats,
-                           long long a, long long b, long long ps, long long pe, float h,
+                           const SparseScores& sp, long long a, long long b, long long ps, long long pe, float h,
                            float min_prom, int lane, float& prom) {
     long long cl = ps, cr = pe;
     float lmin = h, rmin = h;
     bool dl = cl <= a, dr = cr >= b;
     while (!dl || !dr) {
         if (!dl) {
-            const bool stopped = step_left(g, stats, a, cl, h, lmin, lane);
+            const bool stopped = step_left(g, stats, sp, a, cl, h, lmin, lane);
             dl = stopped || cl <= a;
             if (dl && !((h - lmin) >= min_prom)) return false;
         }
         if (!dr) {
-            const bool stopped = step_right(g, stats, b, cr, h, rmin, lane);
+            const bool stopped = step_right(g, stats, sp, b, cr, h, rmin, lane);
             dr = stopped || cr >= b;
             if (dr && !((h - rmin) >= min_prom)) return false;
         }
@@ -170,7 +191,7 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
-             am_peak* __restrict__ out, SegHeader* __restrict__ hdr) {
+             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -188,7 +209,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
     if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; }
     if (b - a < 3) {
-        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; }
+        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = 0.f; }
         return;
     }
     // full tiles [tf, tl) lie completely inside [a, b)
@@ -200,8 +221,8 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
 
     // ---- chunk minimum ----------------------------------------------------
     float mn = FLT_MAX;
-    for (long long i = a + tid; i < head_hi; i += kPeakThreads) mn = fminf(mn, g[i]);
-    for (long long i = tail_lo + tid; i < b; i += kPeakThreads) mn = fminf(mn, g[i]);
+    for (long long i = a + tid; i < head_hi; i += kPeakThreads) mn = fminf(mn, score_for_min(g, sp, i));
+    for (long long i = tail_lo + tid; i < b; i += kPeakThreads) mn = fminf(mn, score_for_min(g, sp, i));
     if (has_full) for (long long t = tf + tid; t < tl; t += kPeakThreads) mn = fminf(mn, stats[t].x);
     mn = wave_min(mn);
     if (lane == 0) red[wv] = mn;
@@ -209,6 +230,13 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     if (tid == 0) seg_min_s = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
     __syncthreads();
     const float seg_min = seg_min_s;
+    // Sparse raw scores are sufficient only if every score that can qualify
+    // (x - seg_min >= min_prom) was written (x >= theta); otherwise report it and
+    // let the host redo this haystack with theta = -inf.
+    if (sp.wflags != nullptr && !((sp.theta - seg_min) < min_prom)) {
+        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; }
+        return;
+    }
 
     // ---- candidate tiles: prominence <= height - chunk_min (monotone f32
     // rounding), so a tile whose maximum fails the test cannot hold a peak ----
@@ -239,11 +267,12 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         // -- local maxima with flat tops whose height can qualify --
         for (long long i = lo + tid; i < hi; i += kPeakThreads) {
             if (i <= a || i >= b - 1) continue;
+            if (!run_written(sp, i)) continue;   // every score there is < theta: cannot qualify
             const float x = g[i];
-            if (!(g[i - 1] < x) || !((x - seg_min) >= min_prom)) continue;
+            if (!((x - seg_min) >= min_prom) || !(score_for_cmp(g, sp, i - 1) < x)) continue;
             long long k = i + 1;
-            while (k < b - 1 && g[k] == x) ++k;
-            if (g[k] < x) {
+            while (k < b - 1 && score_for_cmp(g, sp, k) == x) ++k;
+            if (score_for_cmp(g, sp, k) < x) {
                 const int slot = atomicAdd(&queue_n, 1);
                 if (slot < kQueueCap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
                 else overflow = 1;
@@ -255,7 +284,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         for (int q = wv; q < qn; q += kWaves) {
             const Cand cd = queue[q];
             float prom = 0.0f;
-            const bool keep = prominence(g, stats, a, b, cd.ps, cd.pe, cd.h, min_prom, lane, prom);
+            const bool keep = prominence(g, stats, sp, a, b, cd.ps, cd.pe, cd.h, min_prom, lane, prom);
             if (keep && lane == 0) {
                 const int slot = atomicAdd(&res_n, 1);
                 if (slot < AM_MAX_PEAKS_PER_CHUNK) {
@@ -302,6 +331,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         }
         hdr[blockIdx.x].n = kept;
         hdr[blockIdx.x].overflow = overflow;
+        hdr[blockIdx.x].seg_min = seg_min;
     }
 }
 
@@ -381,10 +411,10 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, SegHeader* d_hdr) {
+                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp) {
     if (nsegs <= 0) return hipSuccess;
     hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_hdr);
+                       min_prom, min_dist, d_out, d_hdr, sp);
     return hipGetLastError();
 }
 

@@ -124,3 +124,60 @@ def test_pcm_downmix_bit_exact(gpu, oracle):
     got = gpu.pcm_s16_stereo_to_mono(lr)
     exp = oracle.pcm_s16_stereo_to_mono(lr)
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_sparse_score_path_after_first_call(gpu, oracle):
+    """The first call with a needle writes every raw score; later calls write
+    raw scores only for tiles with a score >= theta (fused scan).  Both paths
+    must give the oracle's answer, also at the production transform size."""
+    sr = 44100
+    needle, hay = synth_case(oracle, sr, 10.0, 150.0, [20.0, 95.5, 130.0])
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=30.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+    algo = gpu.HipConvolve(needle)
+    first = algo.match(hay, p)
+    second = algo.match(hay, p)
+    third = algo.match(hay, p)
+    assert len(exp) == 3
+    for got in (first, second, third):
+        assert_same(got, exp)
+
+
+def test_theta_certificate_failure_falls_back(gpu, oracle):
+    """A quiet haystack first (high theta learned), then a loud one whose chunk
+    minimum is far lower: the certificate fails and the haystack is redone with
+    every score written; the answer still equals the oracle's."""
+    sr = 44100
+    s = 5 * sr
+    needle = oracle.synth_uniform(2, 0, 0, s)
+    quiet = oracle.synth_uniform(2, 1, 0, 100 * sr, 0.01)
+    quiet[30 * sr:30 * sr + s] += needle
+    loud = oracle.synth_uniform(2, 2, 0, 100 * sr, 2.0)
+    for t in (12, 77):
+        loud[t * sr:t * sr + s] += needle
+    cfg = gpu.Config(chunk_size_s=40.0, overlap_length_s=5.0, distance_s=20.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    for hay in (quiet, quiet, loud, loud, quiet):
+        got = algo.match(hay, p)
+        exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 20.0)
+        assert_same(got, exp)
+
+
+def test_peak_in_chunk_edge_run_sparse(gpu, oracle):
+    """Hits right at chunk starts / ends with the sparse path active."""
+    sr = 44100
+    s = 10 * sr
+    needle = oracle.synth_uniform(4, 0, 0, s)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=30.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    for delta in (-33, -1, 0, 1, 2, 31, 32, 33):
+        hay = oracle.synth_uniform(4, 1, 0, 200 * sr)
+        off = 60 * sr + delta
+        hay[off:off + s] += needle
+        hay[5 * sr:5 * sr + s] += needle
+        got = algo.match(hay, p)
+        exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+        assert_same(got, exp)
