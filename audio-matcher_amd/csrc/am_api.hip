@@ -300,6 +300,7 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
             scan.theta = scan_req->theta;
             scan.seg_c = scan_req->seg_c;
             scan.seg_d = scan_req->seg_d;
+            scan.inv_c = scan.seg_c > 0 ? 1.0 / (double)scan.seg_c : 0.0;
             scan_req->fused = true;
             scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2};
         }

@@ -162,7 +162,7 @@ __device__ __forceinline__ float2 load2_padded(const float* __restrict__ src, lo
 // K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
 // FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
 // holds frequency k1 in natural order.
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
     const int t = threadIdx.x;
@@ -206,18 +206,21 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
         twiddle_brev<16, false>(x0, w);
         twiddle_brev<16, false>(x1, w);
     }
+    // Exchange between the two passes, one column of the pair at a time so that a
+    // workgroup needs 34 KB of LDS (row stride 17 keeps the 8-byte reads of rows
+    // 16 apart on disjoint banks): pass 2 owns a' = hi, b = 0..15.
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
 #pragma unroll
-    for (int ap = 0; ap < 16; ++ap)   // LDS row (a'*16 + b), 16-byte slot cp
-        lds4[(ap * 16 + hi) * 16 + cp] = make_float4(x0[brev<16>(ap)].x, x0[brev<16>(ap)].y,
-                                                     x1[brev<16>(ap)].x, x1[brev<16>(ap)].y);
+    for (int ap = 0; ap < 16; ++ap) lds2[(ap * 16 + hi) * 17 + cp] = x0[brev<16>(ap)];
     __syncthreads();
-    // pass 2 ownership: a' = hi, columns 2cp, 2cp+1, b = 0..15
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-        const float4 v = lds4[(hi * 16 + b) * 16 + cp];
-        x0[b] = make_float2(v.x, v.y);
-        x1[b] = make_float2(v.z, v.w);
-    }
+    for (int b = 0; b < 16; ++b) x0[b] = lds2[(hi * 16 + b) * 17 + cp];
+    __syncthreads();
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) lds2[(ap * 16 + hi) * 17 + cp] = x1[brev<16>(ap)];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x1[b] = lds2[(hi * 16 + b) * 17 + cp];
     dif<16, false>(x0);
     dif<16, false>(x1);
     // k1 = a' + 16*b';  W_N^(n2*k1) = W_N^(n2*a') * (W_N^(16*n2))^b'
@@ -412,14 +415,21 @@ __device__ __forceinline__ float treduce16(const float (&v)[16], int cp) {
 // (i*c + d) score of a reference chunk?  (audio_matcher.rs:104, 119: chunk i
 // covers scores [i*c, i*c + d].)  Such runs are only partly inside a chunk, so
 // the peak pick needs their raw scores, not just their summary.
-__device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, long long d) {
+__device__ __forceinline__ long long mod_recip(long long x, long long c, double inv_c) {
+    // x mod c for 0 <= x < 2^50 through one f64 multiply and a fix-up
+    long long q = (long long)((double)x * inv_c);
+    long long r = x - q * c;
+    if (r < 0) r += c;
+    else if (r >= c) r -= c;
+    return r;
+}
+__device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, long long d, double inv_c) {
     if (c <= 0) return true;
-    const long long q0 = (lo + 31) / c;
-    if (q0 * c >= lo) return true;
-    const long long lo2 = lo - d;
-    if (lo2 + 31 < 0) return false;
-    const long long q1 = (lo2 + 31) / c;
-    return q1 * c >= lo2;
+    // a multiple of c in [lo, lo+31]  <=>  (lo + 31) mod c <= 31
+    if (mod_recip(lo + 31, c, inv_c) <= 31) return true;
+    const long long hi2 = lo + 31 - d;   // i*c + d in [lo, lo+31]  <=>  i*c in [lo-d, lo-d+31]
+    if (hi2 < 0) return false;
+    return mod_recip(hi2, c, inv_c) <= 31;
 }
 
 __device__ __forceinline__ float group16_min(float v) {
@@ -436,7 +446,7 @@ __device__ __forceinline__ float group16_max(float v) {
 // K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     const int t = threadIdx.x;
@@ -476,18 +486,20 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     }
     dif<16, true>(x0);   // b at x[brev(b)]
     dif<16, true>(x1);
+    // exchange, one column of the pair at a time (32 KB of LDS per workgroup);
+    // afterwards ownership is b = hi, a' = 0..15
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
 #pragma unroll
-    for (int b = 0; b < 16; ++b)
-        lds4[(hi * 16 + b) * 16 + cp] = make_float4(x0[brev<16>(b)].x, x0[brev<16>(b)].y,
-                                                    x1[brev<16>(b)].x, x1[brev<16>(b)].y);
+    for (int b = 0; b < 16; ++b) lds2[(hi * 16 + b) * 16 + cp] = x0[brev<16>(b)];
     __syncthreads();
-    // ownership: b = hi, a' = 0..15
 #pragma unroll
-    for (int ap = 0; ap < 16; ++ap) {
-        const float4 v = lds4[(ap * 16 + hi) * 16 + cp];
-        x0[ap] = make_float2(v.x, v.y);
-        x1[ap] = make_float2(v.z, v.w);
-    }
+    for (int ap = 0; ap < 16; ++ap) x0[ap] = lds2[(ap * 16 + hi) * 16 + cp];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[(hi * 16 + b) * 16 + cp] = x1[brev<16>(b)];
+    __syncthreads();
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) x1[ap] = lds2[(ap * 16 + hi) * 16 + cp];
     {
         const float2 w = pl.tw1[hi];
         twiddle_nat<16, true>(x0, w);
@@ -526,8 +538,8 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         // raw scores leave the chip only for tiles that can matter to the peak
         // pick: some score >= theta, or a run that straddles a chunk edge
         const long long rowrun = (long long)t * kN2 + n2_0;   // thread t checks row n1 = t
-        const bool edgeA = rowrun < limA && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d);
-        const bool edgeB = rowrun < limB && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d);
+        const bool edgeA = rowrun < limA && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+        const bool edgeB = rowrun < limB && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         wantA = __syncthreads_or((tmaxA >= scan.theta) || edgeA) != 0;
         wantB = __syncthreads_or((tmaxB >= scan.theta) || edgeB) != 0;
         if (t == 0 && scan.wflags != nullptr) {
@@ -761,7 +773,9 @@ k3_cols_inv_gen(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 
 // ---------------------------------------------------------------------------
 static constexpr int kMaxLds = 160 * 1024;
-static constexpr int kR16Lds = 64 * 1024;
+static constexpr int kR16Lds = 64 * 1024;       // K2: one 8192-point row
+static constexpr int kR16LdsK1 = 256 * 17 * 8;   // K1: one column of the pair at a time, padded rows
+static constexpr int kR16LdsK3 = 256 * 16 * 8;
 
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
 
@@ -774,8 +788,8 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k3_cols_inv_gen<kColsLog>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<false>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<true>, kMaxLds)
-    AM_SET_LDS(k1_cols_fwd_r16, kR16Lds)
-    AM_SET_LDS(k3_cols_inv_r16, kR16Lds)
+    AM_SET_LDS(k1_cols_fwd_r16, kR16LdsK1)
+    AM_SET_LDS(k3_cols_inv_r16, kR16LdsK3)
     AM_SET_LDS(k2_rows_r16<false>, kR16Lds)
     AM_SET_LDS(k2_rows_r16<true>, kR16Lds)
 #undef AM_SET_LDS
@@ -785,7 +799,7 @@ hipError_t fft_kernels_init() {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl)) {
-        hipLaunchKernelGGL(k1_cols_fwd_r16, grid, dim3(256), kR16Lds, st, job, work, pl);
+        hipLaunchKernelGGL(k1_cols_fwd_r16, grid, dim3(256), kR16LdsK1, st, job, work, pl);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
         hipLaunchKernelGGL(k1_cols_fwd_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl);
@@ -822,7 +836,7 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                      const PlanDev& pl, float out_scale, const ScanCfg& scan) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl)) {
-        hipLaunchKernelGGL(k3_cols_inv_r16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16Lds, st, job, work,
+        hipLaunchKernelGGL(k3_cols_inv_r16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                            pl, out_scale, scan);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;

@@ -54,6 +54,7 @@ struct ScanCfg {
     unsigned char* wflags;    // [block][column tile] = 1 when the tile's raw scores were written
     float theta;              // raw scores are written for tiles with a score >= theta ...
     long long seg_c, seg_d;   // ... and for runs that hold score i*seg_c or i*seg_c + seg_d (chunk edges)
+    double inv_c;             // 1.0 / seg_c
 };
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan);

@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU sample (0 = one per thread)")
     ap.add_argument("--log-n", type=int, default=0)
     ap.add_argument("--pairs-per-group", type=int, default=0)
+    ap.add_argument("--k2-variant", type=int, default=-1)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,6 +118,8 @@ def main():
         am.set_option("log_n", args.log_n)
     if args.pairs_per_group:
         am.set_option("pairs_per_group", args.pairs_per_group)
+    if args.k2_variant >= 0:
+        am.set_option("k2_variant", args.k2_variant)
 
     needle, algo, hays = make_inputs(am, device, args.haystacks_per_rank, rank)
     cfg = am.Config(chunk_size_s=CHUNK_S, overlap_length_s=NEEDLE_S, distance_s=480.0, prominence=0.13)
