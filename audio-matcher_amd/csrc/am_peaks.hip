@@ -356,8 +356,8 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
 }
 
-// counter-based test signal; must stay bit-identical to
-// orc_synth_uniform in oracle/oracle.c
+// counter-based test signal: 24 hashed bits -> [-1, 1) exactly, times amp.
+// tests/ compare it bit for bit with the checker's own generator.
 __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ out, uint32_t seed, uint32_t stream,
                                                     uint64_t first, long long n, float amp) {
     const uint32_t key = fmix32(seed * 0x9E3779B9u + stream * 0x7F4A7C15u + 0x01234567u);

@@ -1,0 +1,134 @@
+// audiomatch.hpp -- header-only C++17 host mirror of the reference's matcher
+// interface (the reference is compiled Rust; no Rust toolchain exists in the
+// build image, so the host side above the C ABI is C++):
+//
+//   trait CorrelateAlgo<f32>          src/matcher/audio_matcher.rs:65-76
+//   enum Mode                         src/matcher/audio_matcher.rs:55-59
+//   struct Config / PeakConfig        src/matcher/audio_matcher.rs:25-53
+//   LibConvolve::new / MyConvolve::new  :289 / :396
+//   fn calc_chunks(...)               src/matcher/audio_matcher.rs:88-141
+//   find_peaks::Peak<f32>             as consumed at matcher/mod.rs:110-129
+//
+// Same names, argument meaning and error behaviour: where the trait returns
+// Err(Box<dyn Error>) these functions throw audiomatch::Error (calc_chunks in
+// the reference unwraps, i.e. panics, audio_matcher.rs:122).  Everything is
+// forwarded to libaudiomatch_amd.so (include/audiomatch.h); there is no CPU path.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "audiomatch.h"
+
+namespace audiomatch {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc != AM_OK) throw Error(rc, std::string("audiomatch: ") + am_last_error_string());
+}
+
+enum class Mode : int { Full = AM_MODE_FULL, Same = AM_MODE_SAME, Valid = AM_MODE_VALID };
+
+// find_peaks::Peak<f32>: position is the half-open range [start, end)
+struct Peak {
+    std::size_t start = 0, end = 0;
+    float height = 0.f;
+    float prominence = 0.f;   // Option<f32>; always Some on this path
+};
+
+// audio_matcher.rs:25-53, durations in seconds
+struct Config {
+    double chunk_size = 60.0;        // matcher/args.rs:70-72
+    double overlap_length = 0.0;     // Config::from_args: the snippet duration (:41)
+    double distance = 8 * 60.0;      // matcher/args.rs:73-76
+    float prominence = 13.0f / 100;  // args.prominence / 100 (:44)
+
+    am_match_params params(std::uint32_t sr, bool scale) const {
+        am_match_params p{};
+        p.sr = sr;
+        p.chunk = static_cast<std::uint64_t>(std::llround(chunk_size * sr));       // :100
+        p.overlap = static_cast<std::uint64_t>(std::llround(overlap_length * sr)); // :99
+        p.min_prominence = prominence;
+        p.min_distance = static_cast<std::uint64_t>(distance) * sr;                // distance.as_secs() * sr (:228)
+        p.overshadow_distance_s = distance;
+        p.scale = scale ? AM_SCALE_LIB : AM_SCALE_NONE;                            // production passes true (mod.rs:85)
+        return p;
+    }
+};
+
+// trait CorrelateAlgo<f32> (audio_matcher.rs:65-76)
+class CorrelateAlgo {
+public:
+    virtual ~CorrelateAlgo() = default;
+    virtual float inverse_sample_auto_correlation() const = 0;
+    virtual std::vector<float> correlate_with_sample(const float* within, std::size_t len, Mode mode,
+                                                     bool scale) const = 0;
+    // provided method `scale` (:73-75)
+    void scale(std::vector<float>& data) const {
+        const float f = inverse_sample_auto_correlation();
+        for (float& v : data) v *= f;
+    }
+};
+
+// The HIP-backed implementation: drop-in for LibConvolve (production, mod.rs:34).
+class HipConvolve final : public CorrelateAlgo {
+public:
+    explicit HipConvolve(const std::vector<float>& sample_data, int device = 0) {
+        check(am_needle_create(device, sample_data.data(), sample_data.size(), &h_));
+    }
+    HipConvolve(const HipConvolve&) = delete;
+    HipConvolve& operator=(const HipConvolve&) = delete;
+    HipConvolve(HipConvolve&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    ~HipConvolve() override { am_needle_destroy(h_); }
+
+    float inverse_sample_auto_correlation() const override {
+        float v = 0.f;
+        check(am_needle_inv_autocorr(h_, &v));
+        return v;
+    }
+    std::vector<float> correlate_with_sample(const float* within, std::size_t len, Mode mode,
+                                             bool scale) const override {
+        std::size_t s = 0, n = 0;
+        check(am_needle_len(h_, &s));
+        check(am_correlate_len(len, s, static_cast<int>(mode), &n));
+        std::vector<float> out(n);
+        check(am_correlate(h_, within, len, static_cast<int>(mode), scale ? AM_SCALE_LIB : AM_SCALE_NONE,
+                           out.data(), out.size(), &n));
+        return out;
+    }
+    const am_needle* handle() const { return h_; }
+
+private:
+    am_needle* h_ = nullptr;
+};
+
+// calc_chunks(sr, m_samples, &algo, scale, config) (audio_matcher.rs:88-141):
+// peaks sorted by position.start, overshadowed neighbours removed.
+inline std::vector<Peak> calc_chunks(std::uint16_t sr, const float* m_samples, std::size_t len,
+                                     const HipConvolve& algo_with_sample, bool scale, const Config& config) {
+    const am_match_params p = config.params(sr, scale);
+    std::vector<am_peak> buf(256);
+    std::size_t n = 0;
+    int rc = am_match(algo_with_sample.handle(), m_samples, len, &p, buf.data(), buf.size(), &n);
+    if (rc == AM_ERR_CAPACITY) {
+        buf.resize(n);
+        rc = am_match(algo_with_sample.handle(), m_samples, len, &p, buf.data(), buf.size(), &n);
+    }
+    check(rc);
+    std::vector<Peak> out(n);
+    for (std::size_t i = 0; i < n; ++i)
+        out[i] = Peak{static_cast<std::size_t>(buf[i].start), static_cast<std::size_t>(buf[i].end),
+                      buf[i].height, buf[i].prominence};
+    return out;
+}
+
+}  // namespace audiomatch

@@ -1,0 +1,99 @@
+"""CPU tests: the C-ABI library loads and exports every symbol the header
+declares, fails loudly without a device, and the host-side mirror of the
+reference interface behaves like the reference (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(ROOT, "include", "audiomatch.h")
+
+
+def header_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree(amlib):
+    assert header_symbols() == amlib.declared_symbols()
+
+
+def test_library_exports_every_declared_symbol(amlib):
+    lib = C.CDLL(amlib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", amlib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (am_[a-z0-9_]+)\b", out))
+    assert set(header_symbols()) <= exported
+    assert amlib.lib().am_abi_version() == 1
+
+
+def test_header_cites_reference_for_every_entry_point():
+    txt = open(HEADER).read()
+    assert txt.count("audio_matcher.rs") >= 12 and "mp3_reader.rs" in txt and "matcher/mod.rs" in txt
+
+
+def test_pure_host_entry_points(amlib):
+    n = C.c_size_t(0)
+    L = amlib.lib()
+    assert L.am_correlate_len(20, 3, int(amlib.Mode.Valid), C.byref(n)) == 0 and n.value == 18
+    assert L.am_correlate_len(20, 3, int(amlib.Mode.Full), C.byref(n)) == 0 and n.value == 22
+    assert L.am_correlate_len(20, 3, int(amlib.Mode.Same), C.byref(n)) == 0 and n.value == 20
+    assert L.am_correlate_len(3, 7, int(amlib.Mode.Valid), C.byref(n)) == 0 and n.value == 1   # saturating_sub + 1
+    assert L.am_correlate_len(0, 3, 2, C.byref(n)) == amlib.AM_ERR_INVALID_ARG
+    assert L.am_set_option(b"log_n", 99) == amlib.AM_ERR_INVALID_ARG
+    assert L.am_set_option(b"nonsense", 1) == amlib.AM_ERR_INVALID_ARG
+    assert b"unknown" in L.am_last_error_string()
+    assert L.am_set_option(b"log_n", 0) == 0
+    assert amlib.get_option("pairs_per_group") >= 1
+
+
+def test_no_device_fails_loudly(amlib):
+    """Without a GPU every compute entry point must return an error: no CPU fallback."""
+    if amlib.device_count() > 0:
+        pytest.skip("a GPU is visible; covered by the gpu tests")
+    with pytest.raises(amlib.AudioMatchError) as ei:
+        amlib.HipConvolve([1.0, 2.0, 3.0])
+    assert ei.value.code == amlib.AM_ERR_NO_DEVICE
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.find_peaks([0.0, 1.0, 0.0], 0.0)
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.pcm_s16_stereo_to_mono(np.zeros(8, np.int16))
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped sources must not reference oracle/ (checker only)."""
+    for sub in ("audio-matcher_amd/csrc", "audio-matcher_amd/python", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".hip", ".h", ".hpp", ".py", ".cpp")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert "pyoracle" not in txt and "liboracle" not in txt and "orc_" not in txt, f
+
+
+def test_config_mirrors_reference_defaults(amlib):
+    fx = __import__("json").load(open(os.path.join(ROOT, "tests", "golden", "fixtures.json")))["defaults"]
+    cfg = amlib.Config(overlap_length_s=10.0)
+    p = cfg.params(44100, amlib.Scale.LIB)
+    assert abs(p.min_prominence - fx["prominence"]) < 1e-7
+    assert p.chunk == fx["chunk_s"] * 44100 and p.overlap == 441000
+    assert p.min_distance == fx["min_distance_samples_at_44100"]
+    assert p.overshadow_distance_s == fx["distance_s"] and p.scale == 1
+    # (secs * sr).round(): half away from zero (audio_matcher.rs:99-100)
+    assert amlib.Config(chunk_size_s=0.5).params(3, 0).chunk == 2
+    # distance.as_secs() truncates to whole seconds before * sr (audio_matcher.rs:228)
+    assert amlib.Config(distance_s=2.9).params(100, 0).min_distance == 200
+
+
+def test_cpp_host_mirror_compiles():
+    """include/audiomatch.hpp (C++ mirror of CorrelateAlgo / calc_chunks) is valid C++17."""
+    hpp = os.path.join(ROOT, "include", "audiomatch.hpp")
+    src = '#include "audiomatch.hpp"\nint main() { audiomatch::Config c; (void)c; return 0; }\n'
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-"],
+                   input=src, text=True, check=True)
+    assert os.path.exists(hpp)

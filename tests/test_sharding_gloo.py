@@ -1,0 +1,62 @@
+"""CPU test of the N > 1 path: two gloo ranks shard a haystack batch with no
+data-path collective, gather the peak lists on the host and agree with the
+single-process answer.  (On the GPU box the same helpers drive bench.py; here the
+per-haystack matcher is the CPU oracle, which is what a rank would be checked
+against.)"""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, os.path.join(%(root)r, "audio-matcher_amd", "python"))
+    sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+    import torch.distributed as dist
+    import pyoracle as po
+    from audiomatch_amd import sharding
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sr, s, n_hay = 4000, 4000, 5
+    needle = po.synth_uniform(1, 0, 0, s)
+    local = {}
+    for k in sharding.shard_indices(n_hay, rank, world):
+        hay = po.synth_uniform(1, k + 1, 0, 20 * sr)
+        off = (3 + 2 * k) * sr + 17 * k
+        hay[off:off + s] += needle
+        pk = po.calc_chunks(sr, hay, needle, 8 * sr, s, 0.3, 480 * sr, 480.0)
+        local[k] = [p[0] for p in pk]
+    dist.barrier()
+    merged = sharding.gather_results(local, dist)
+    t = sharding.max_over_ranks(1.0 + rank, dist)
+    if rank == 0:
+        print(json.dumps({"merged": {str(k): v for k, v in sorted(merged.items())}, "tmax": t}))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    import json
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    sr = 4000
+    assert res["tmax"] == 2.0
+    assert res["merged"] == {str(k): [(3 + 2 * k) * sr + 17 * k] for k in range(5)}
+
+
+def test_shard_indices_partition():
+    sys.path.insert(0, os.path.join(ROOT, "audio-matcher_amd", "python"))
+    from audiomatch_amd import sharding
+    for world in (1, 2, 3, 8):
+        seen = sorted(k for r in range(world) for k in sharding.shard_indices(1000, r, world))
+        assert seen == list(range(1000))
+        assert all(sharding.owner_of(k, world) == r for r in range(world) for k in sharding.shard_indices(50, r, world))
