@@ -239,7 +239,9 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
 
 static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
     Ctx* c = h->ctx;
-    auto it = h->spectra.find(pl->dev.logN);
+    // the two K2 forms keep the spectrum in different (register-order) layouts
+    const int key = pl->dev.logN * 4 + (plan_is_r16(pl->dev) ? 1 + g_k2_variant : 0);
+    auto it = h->spectra.find(key);
     if (it != h->spectra.end()) { *out = it->second; return AM_OK; }
     const size_t N = (size_t)1 << pl->dev.logN;
     int rc = c->work.ensure(std::max<size_t>(N * sizeof(float2), c->work.cap));
@@ -255,7 +257,7 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
         AM_HIP(launch_k2_spectrum(c->stream, (float2*)c->work.p, hc, pl->dev));
     }
     AM_HIP(hipStreamSynchronize(c->stream));
-    h->spectra[pl->dev.logN] = hc;
+    h->spectra[key] = hc;
     *out = hc;
     return AM_OK;
 }
@@ -864,6 +866,10 @@ int am_set_option(const char* key, long long value) {
         if (value != 0 && (value < kLogNMin || value > kLogNMax)) return fail(AM_ERR_INVALID_ARG, "log_n out of range");
         g_opt_log_n = value; return AM_OK;
     }
+    if (!strcmp(key, "k2_variant")) {
+        if (value < 0 || value > 1) return fail(AM_ERR_INVALID_ARG, "k2_variant must be 0 or 1");
+        g_k2_variant = (int)value; return AM_OK;
+    }
     if (!strcmp(key, "pairs_per_group")) {
         if (value < 1 || value > 64) return fail(AM_ERR_INVALID_ARG, "pairs_per_group out of range");
         g_opt_pairs_per_group = value; return AM_OK;
@@ -874,6 +880,7 @@ int am_get_option(const char* key, long long* value) {
     if (!key || !value) return fail(AM_ERR_INVALID_ARG, "null pointer");
     if (!strcmp(key, "log_n")) { *value = g_opt_log_n; return AM_OK; }
     if (!strcmp(key, "pairs_per_group")) { *value = g_opt_pairs_per_group; return AM_OK; }
+    if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }
 

@@ -382,6 +382,134 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
                                                      x1[brev<16>(a)].x, x1[brev<16>(a)].y));
 }
 
+// Lane exchanges as DPP moves (VALU) rather than ds_bpermute (LDS pipe).
+template <int CTRL, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                  CTRL, 0xF, BANK_MASK, false));
+}
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v, v); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v, v); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_xor8(float v) { return dpp_mov<0x128>(v, v); }  // row_ror:8
+__device__ __forceinline__ float lane_xor4(float v) {
+    // rotate by 4 one way for the lanes of banks 0,2 and the other way for banks 1,3
+    const float a = dpp_mov<0x12C, 0x5>(v, v);   // row_ror:12 into banks 0 and 2
+    return dpp_mov<0x124, 0xA>(a, v);            // row_ror:4  into banks 1 and 3
+}
+__device__ __forceinline__ float2 lane_xor1(float2 v) { return make_float2(lane_xor1(v.x), lane_xor1(v.y)); }
+
+// K2, 512-thread form: the same 16 x 16 x 32 factorisation with 16 points per
+// thread, so that a computing workgroup keeps two waves on every SIMD (a lone
+// wave issues VALU at half rate) and a CU holds 16 waves.  The radix-32 pass is
+// shared by lane pairs: one radix-2 stage across the pair (DPP), then a private
+// radix-16.
+__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
+    f32x2 o; o.x = v.x; o.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
+}
+
+template <bool SPECTRUM>
+__global__ void __launch_bounds__(512, 4)
+k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl,
+             unsigned npairs) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    const int t = threadIdx.x;
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned row = (seq / npairs) * 8u + xcd, slot = seq % npairs;
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
+    const unsigned voff = (unsigned)t * 8u;
+    float2 x[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) x[a] = buf_load2(rrow, voff, a * 4096);   // element a*512 + t
+    // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = t ----
+    dif<16, false>(x);
+    const float2 wj = pl.tw2[t];
+    twiddle_brev<16, false>(x, wj);
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) lds2[ap * 512 + t] = x[brev<16>(ap)];   // L1[a'][j]
+    __syncthreads();
+    // ---- pass 2 over b (stride 32): a' = t >> 5, c = t & 31; twiddle W_512^(c*b') ----
+    const int ap2 = t >> 5, c2 = t & 31;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x[b] = lds2[ap2 * 512 + b * 32 + c2];
+    dif<16, false>(x);
+    const float2 wc = pl.tw2[16 * c2];
+    twiddle_brev<16, false>(x, wc);
+    __syncthreads();
+    // L2: row u = a'*16 + b' (32 points), 8-byte slot (c & 16) | ((c & 15) ^ b')
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp)
+        lds2[(ap2 * 16 + bp) * 32 + ((c2 & 16) | ((c2 & 15) ^ bp))] = x[brev<16>(bp)];
+    __syncthreads();
+    // ---- pass 3 over c: lane pair (u, half) holds c = half*16 + i ----
+    const int u = t >> 1, half = t & 1;
+    const float sgn = half ? -1.0f : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = lds2[u * 32 + (half * 16 + (i ^ (u & 15)))];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {   // radix-2 stage across the pair: c <-> c + 16
+        const float2 p = lane_xor1(x[i]);
+        x[i] = make_float2(fmaf(sgn, x[i].x, p.x), fmaf(sgn, x[i].y, p.y));   // half 0: sum, half 1: x[c] - x[c+16]
+    }
+    if (half) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) x[i] = mul_w32<false>(x[i], i);   // W_32^c on the difference branch
+    }
+    dif<16, false>(x);   // half 0: even frequencies 2m, half 1: odd 2m+1, at x[brev(m)]
+    const size_t hoff2 = (size_t)row * kN2;
+    if (SPECTRUM) {
+        const float invN = 1.0f / (float)(1u << pl.logN);
+        const __amdgpu_buffer_rsrc_t rho = make_rsrc(hc_out + hoff2, kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) buf_store2(rho, voff, i * 4096, make_float2(x[i].x * invN, -x[i].y * invN));
+        return;
+    }
+    {   // pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438)
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(hc + hoff2, kN2 * 8);
+        float2 h[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = buf_load2(rh, voff, i * 4096);
+        float2 q[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q[brev<16>(i)] = cmul(x[i], h[i]);   // natural frequency order m
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = q[i];
+    }
+    // ---- inverse pass 3: private inverse radix-16, then the radix-2 stage across the pair ----
+    dif<16, true>(x);   // time index i at x[brev(i)] (half 0: e[i], half 1: o[i])
+    if (half) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) x[brev<16>(i)] = mul_w32<true>(x[brev<16>(i)], i);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float2 v = x[brev<16>(i)];
+        const float2 p = lane_xor1(v);
+        // half 0: e + o' -> c = i;  half 1: e - o' -> c = 16 + i
+        const float2 r = make_float2(fmaf(sgn, v.x, p.x), fmaf(sgn, v.y, p.y));
+        lds2[u * 32 + (half * 16 + (i ^ (u & 15)))] = r;   // the pair's own row: no barrier needed before
+    }
+    __syncthreads();
+    // ---- inverse pass 2 over b' ----
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) x[bp] = lds2[(ap2 * 16 + bp) * 32 + ((c2 & 16) | ((c2 & 15) ^ bp))];
+    twiddle_nat<16, true>(x, wc);
+    dif<16, true>(x);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[ap2 * 512 + b * 32 + c2] = x[brev<16>(b)];
+    __syncthreads();
+    // ---- inverse pass 1 over a' ----
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) x[ap] = lds2[ap * 512 + t];
+    twiddle_nat<16, true>(x, wj);
+    dif<16, true>(x);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) buf_store2(rrow, voff, a * 4096, x[brev<16>(a)]);
+}
+
 // Reduction across the 16 lanes of a group of 16 per-lane values v[0..15]
 // (lane cp ends up with the reduction of v[cp]): log-step exchange in which
 // every step halves the rows a lane still carries.
@@ -391,23 +519,23 @@ __device__ __forceinline__ float treduce16(const float (&v)[16], int cp) {
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         const float send = (cp & 8) ? v[a] : v[a + 8], keep = (cp & 8) ? v[a + 8] : v[a];
-        const float r = __shfl_xor(send, 8);
+        const float r = lane_xor8(send);
         w8[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float send = (cp & 4) ? w8[a] : w8[a + 4], keep = (cp & 4) ? w8[a + 4] : w8[a];
-        const float r = __shfl_xor(send, 4);
+        const float r = lane_xor4(send);
         w4[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const float send = (cp & 2) ? w4[a] : w4[a + 2], keep = (cp & 2) ? w4[a + 2] : w4[a];
-        const float r = __shfl_xor(send, 2);
+        const float r = lane_xor2(send);
         w2[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
     }
     const float send = (cp & 1) ? w2[0] : w2[1], keep = (cp & 1) ? w2[1] : w2[0];
-    const float r = __shfl_xor(send, 1);
+    const float r = lane_xor1(send);
     return MAX ? fmaxf(keep, r) : fminf(keep, r);
 }
 
@@ -777,6 +905,10 @@ static constexpr int kR16Lds = 64 * 1024;       // K2: one 8192-point row
 static constexpr int kR16LdsK1 = 256 * 17 * 8;   // K1: one column of the pair at a time, padded rows
 static constexpr int kR16LdsK3 = 256 * 16 * 8;
 
+// 0 = 256-thread K2 (32 points per thread), 1 = 512-thread K2 (16 points per thread).
+// The needle spectrum layout differs between the two (the cache is keyed by it).
+int g_k2_variant = 0;
+
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
 
 hipError_t fft_kernels_init() {
@@ -792,6 +924,8 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k3_cols_inv_r16, kR16LdsK3)
     AM_SET_LDS(k2_rows_r16<false>, kR16Lds)
     AM_SET_LDS(k2_rows_r16<true>, kR16Lds)
+    AM_SET_LDS(k2_rows_p512<false>, kR16Lds)
+    AM_SET_LDS(k2_rows_p512<true>, kR16Lds)
 #undef AM_SET_LDS
     return hipSuccess;
 }
@@ -809,7 +943,10 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
 
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, npairs);
-    if (plan_is_r16(pl)) {
+    if (plan_is_r16(pl) && g_k2_variant == 1) {
+        hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << pl.logN1), dim3(512), kR16Lds, st, work, hc,
+                           (float2*)nullptr, pl, (unsigned)npairs);
+    } else if (plan_is_r16(pl)) {
         hipLaunchKernelGGL(k2_rows_r16<false>, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                            (float2*)nullptr, pl, (unsigned)npairs);
     } else {
@@ -821,7 +958,10 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
 
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, 1);
-    if (plan_is_r16(pl)) {
+    if (plan_is_r16(pl) && g_k2_variant == 1) {
+        hipLaunchKernelGGL(k2_rows_p512<true>, dim3(1u << pl.logN1), dim3(512), kR16Lds, st, work, (const float2*)nullptr,
+                           hc_out, pl, 1u);
+    } else if (plan_is_r16(pl)) {
         hipLaunchKernelGGL(k2_rows_r16<true>, dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u);
     } else {

@@ -59,6 +59,7 @@ struct ScanCfg {
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan);
 bool plan_is_r16(const PlanDev& pl);
+extern int g_k2_variant;
 hipError_t fft_kernels_init();
 
 hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats);

@@ -80,6 +80,20 @@ def cpu_baseline(n_chunks: int, threads: int):
                       f"pad {chunk + 2 * s - 1} (Bluestein, f32), {dt:.2f} s wall, offsets_ok={ok}"}
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary
+    (profiles/pmc_traffic.json, written by tools/pmc_summary.py from separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command, with the gfx950
+    corrections of MI355X_MICROARCH.md); None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,10 +192,12 @@ def main():
     out_count = h - s + 1
     nblocks = -(-out_count // hop)
     npairs = (nblocks + 1) // 2
+    # algorithmic bytes per step and kernel (DESIGN.md "Kernels"): every launch
+    # covers all pairs of one haystack
     per_step_bytes = {
         "k1_cols_fwd": npairs * n_fft * (8 + 8),          # two f32 blocks in, complex out
         "k2_rows": npairs * n_fft * (8 + 8 + 8),          # complex in, needle spectrum in, complex out
-        "k3_cols_inv": npairs * n_fft * 8 + out_count * 4,  # complex in, f32 scores out
+        "k3_cols_inv": npairs * n_fft * 8 + (out_count // 32) * 8,  # complex in, (min,max) per 32 scores out
     }
     dom = max(per_step_bytes, key=lambda n_: kern[n_][0])
     dom_ms, dom_launches = kern[dom]
@@ -200,7 +216,7 @@ def main():
                    "needle_samples": s, "haystack_samples": h, "fft_log2": log_n, "hop": hop,
                    "sharding": f"{world} rank(s), independent haystacks, no collective"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                      "bytes_per_launch": dom_bytes_per_launch, "avg_launch_us": dom_avg_s * 1e6,
                      "launches": dom_launches},
         "roofline_pipeline": {"bound": "hbm", "achieved": pipe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -208,6 +224,19 @@ def main():
                               "bytes_per_sample": SURVEY_BYTES_PER_SAMPLE,
                               "kernel_ms_per_step": {n_: v[0] / args.steps for n_, v in kern.items()}},
     }
+    if world == 1:
+        # the boundary also accepts host buffers (am_match): report the PCIe-inclusive
+        # rate next to the resident one (never used as `value`)
+        k0, buf0 = hays[0]
+        host = buf0.to_numpy("float32", h)
+        algo.match(host, params)
+        t0 = time.perf_counter()
+        pk = algo.match(host, params)
+        te = time.perf_counter() - t0
+        assert [p.start for p in pk] == plant_offsets(k0)
+        out["end_to_end_host_buffer"] = {"value": h / te, "unit": "samples/s",
+                                         "note": "am_match from pageable host memory: H2D copy + match, 1 haystack"}
+        del host
     if world == 1 and not args.no_cpu_baseline:
         threads = min(os.cpu_count() or 1, 16)
         chunks = args.cpu_chunks or threads

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) row_kernel(float4* src, float4* dst, floa
     } else {
         float4* o = (MODE == 1) ? dst : src;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) o[base + a * 256 + threadIdx.x] = v[a];
+        for (int a = 0; a < 16; ++a) { v[a].x += 1.0f; o[base + a * 256 + threadIdx.x] = v[a]; }
     }
 }
 // column pattern (K1 write / K3 read): WG handles 32 columns x 256 rows of a [256][8192] float2 matrix:

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json.
+
+Usage: python tools/pmc_summary.py <dir with FETCH_SIZE/ and WRITE_SIZE/ pass outputs> <out.json>
+
+Units and corrections (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE / WRITE_SIZE are
+in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced streaming read (16 B per lane) and WRITE_SIZE is exact for 16-B-per-lane
+stores.  K1's f32 input loads are 8 B per lane, for which the guide gives no
+calibration: its read figure is marked "uncalibrated".
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_r16", "k2_rows": "k2_rows_r16<false>", "k3_cols_inv": "k3_cols_inv_r16",
+        "tile_stats": "stats_reduce", "peaks": "peaks_kernel"}
+
+
+def load(pass_dir, counter):
+    files = glob.glob(f"{pass_dir}/**/*_counter_collection.csv", recursive=True)
+    vals = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                vals[r["Kernel_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
+    return vals
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    fetch = load(f"{root}/FETCH_SIZE", "FETCH_SIZE")
+    write = load(f"{root}/WRITE_SIZE", "WRITE_SIZE")
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1",
+           "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 for 16-B-per-lane streaming reads (gfx950)",
+           "kernels": {}}
+    for key, pat in KEYS.items():
+        def pick(vals):
+            best = []
+            for name, lst in vals.items():
+                if pat in name:
+                    gmax = max(g for _, g in lst)          # full-size launches only (skip the 1-pair needle launch)
+                    best += [v for v, g in lst if g == gmax]
+            return sum(best) / len(best) if best else None
+        f, w = pick(fetch), pick(write)
+        if f is None or w is None:
+            continue
+        rd = f * 1024 * 2
+        wr = w * 1024
+        res["kernels"][key] = {"fetch_size_kib": f, "write_size_kib": w, "read_bytes": rd, "write_bytes": wr,
+                               "hbm_bytes_per_launch": rd + wr,
+                               "note": "read side uncalibrated (8 B/lane loads)" if key == "k1_cols_fwd" else ""}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
