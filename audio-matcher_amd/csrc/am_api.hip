@@ -117,6 +117,8 @@ static int get_ctx(int device, Ctx** out) {
     auto it = g_ctx.find(device);
     if (it != g_ctx.end()) { *out = it->second; AM_HIP(hipSetDevice(device)); return AM_OK; }
     AM_HIP(hipSetDevice(device));
+    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // may fail if the primary context is already active: harmless
+    (void)hipGetLastError();
     if (!g_kernels_ready) {
         AM_HIP(fft_kernels_init());
         g_kernels_ready = true;
@@ -293,7 +295,7 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
-        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2};
+        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         if (plan_is_r16(pl->dev) && (hop % kTile) == 0) {
             if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
             if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
@@ -304,7 +306,7 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
             scan.seg_d = scan_req->seg_d;
             scan.inv_c = scan.seg_c > 0 ? 1.0 / (double)scan.seg_c : 0.0;
             scan_req->fused = true;
-            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2};
+            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         }
     }
     Job job{};
@@ -367,7 +369,7 @@ static bool is_overshadowed(const am_peak& element, const am_peak* other, uint32
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
                        float min_prom, long long min_dist, const ScanRequest* scan) {
     const float2* d_stats32 = (scan && scan->fused) ? scan->sparse.stats32 : nullptr;
-    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5};
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;

@@ -80,6 +80,7 @@ struct SparseScores {
     const float2* stats32;
     float theta;
     int hop, log_n2;
+    double inv_hop;
 };
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,

@@ -29,6 +29,7 @@ namespace am {
 constexpr int kPeakThreads = 256;
 constexpr int kWaves = kPeakThreads / 64;
 constexpr int kQueueCap = kTile;  // local maxima of one tile (<= kTile/2, head/tail pieces < kTile)
+constexpr int kGroup = 8;         // tiles per lane in the coarse step of a prominence walk
 constexpr int kCandCap = 1024;    // candidate tiles listed per chunk before falling back to all tiles
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -82,8 +83,12 @@ struct Cand { long long ps, pe; float h; };
 // else only the per-32 summary exists.
 __device__ __forceinline__ bool run_written(const SparseScores& sp, long long idx) {
     if (sp.wflags == nullptr) return true;
-    const long long blk = idx / sp.hop;
-    const unsigned n = (unsigned)(idx - blk * sp.hop);
+    // idx / hop through one f64 multiply and a fix-up (idx < 2^50)
+    long long blk = (long long)((double)idx * sp.inv_hop);
+    long long rem = idx - blk * sp.hop;
+    if (rem < 0) { rem += sp.hop; --blk; }
+    else if (rem >= sp.hop) { rem -= sp.hop; ++blk; }
+    const unsigned n = (unsigned)rem;
     const unsigned tile = (n & ((1u << sp.log_n2) - 1u)) >> 5;
     return sp.wflags[blk * (long long)(1 << (sp.log_n2 - 5)) + tile] != 0;
 }
@@ -104,6 +109,24 @@ __device__ __forceinline__ float score_for_cmp(const float* __restrict__ g, cons
 __device__ __forceinline__ bool step_left(const float* __restrict__ g, const float2* __restrict__ stats,
                                           const SparseScores& sp,
                                           long long a, long long& cur, float h, float& vmin, int lane) {
+    // coarse skip: every lane summarises a group of kGroup tiles (64 groups per step)
+    if ((cur % kTile) == 0 && cur - (long long)kGroup * kTile >= a) {
+        const long long t1 = cur / kTile - (long long)kGroup * lane;      // group = tiles [t1 - kGroup, t1)
+        const bool valid = (t1 - kGroup) * (long long)kTile >= a;
+        float gmn = FLT_MAX, gmx = -FLT_MAX;
+        if (valid) {
+#pragma unroll
+            for (int k = 1; k <= kGroup; ++k) { const float2 st = stats[t1 - k]; gmn = fminf(gmn, st.x); gmx = fmaxf(gmx, st.y); }
+        }
+        const unsigned long long blocked = __ballot(valid && gmx > h);
+        const int nvalid = __popcll(__ballot(valid));
+        const int nskip = blocked ? (__ffsll((long long)blocked) - 1) : nvalid;
+        if (nskip > 0) {
+            vmin = fminf(vmin, wave_min(lane < nskip ? gmn : FLT_MAX));
+            cur -= (long long)nskip * kGroup * kTile;
+            return false;
+        }
+    }
     if ((cur % kTile) == 0 && cur - kTile >= a) {
         const long long t = cur / kTile - 1 - lane;
         const bool valid = t >= 0 && t * (long long)kTile >= a;
@@ -120,6 +143,22 @@ __device__ __forceinline__ bool step_left(const float* __restrict__ g, const flo
     }
     const long long tile_lo = ((cur - 1) / kTile) * kTile;
     const long long lo = tile_lo > a ? tile_lo : a;
+    // run-level skip through K3's exact (min,max) per 32 scores (stays inside the
+    // current tile so that tile-level skipping resumes at its boundary)
+    if (sp.stats32 != nullptr && (cur & 31) == 0 && cur - 32 >= lo) {
+        const long long r = (cur >> 5) - 1 - lane;
+        const bool valid = r * 32 >= lo;
+        float2 st = make_float2(FLT_MAX, -FLT_MAX);
+        if (valid) st = sp.stats32[r];
+        const unsigned long long blocked = __ballot(valid && st.y > h);
+        const int nvalid = __popcll(__ballot(valid));
+        const int nskip = blocked ? (__ffsll((long long)blocked) - 1) : nvalid;
+        if (nskip > 0) {
+            vmin = fminf(vmin, wave_min(lane < nskip ? st.x : FLT_MAX));
+            cur -= (long long)nskip * 32;
+            return false;
+        }
+    }
     const long long idx = cur - 1 - lane;
     const bool valid = idx >= lo;
     const float v = valid ? score_for_min(g, sp, idx) : 0.0f;
@@ -135,6 +174,23 @@ __device__ __forceinline__ bool step_left(const float* __restrict__ g, const flo
 __device__ __forceinline__ bool step_right(const float* __restrict__ g, const float2* __restrict__ stats,
                                            const SparseScores& sp,
                                            long long b, long long& cur, float h, float& vmin, int lane) {
+    if ((cur % kTile) == 0 && cur + (long long)kGroup * kTile <= b) {
+        const long long t0 = cur / kTile + (long long)kGroup * lane;      // group = tiles [t0, t0 + kGroup)
+        const bool valid = (t0 + kGroup) * (long long)kTile <= b;
+        float gmn = FLT_MAX, gmx = -FLT_MAX;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) { const float2 st = stats[t0 + k]; gmn = fminf(gmn, st.x); gmx = fmaxf(gmx, st.y); }
+        }
+        const unsigned long long blocked = __ballot(valid && gmx > h);
+        const int nvalid = __popcll(__ballot(valid));
+        const int nskip = blocked ? (__ffsll((long long)blocked) - 1) : nvalid;
+        if (nskip > 0) {
+            vmin = fminf(vmin, wave_min(lane < nskip ? gmn : FLT_MAX));
+            cur += (long long)nskip * kGroup * kTile;
+            return false;
+        }
+    }
     if ((cur % kTile) == 0 && cur + kTile <= b) {
         const long long t = cur / kTile + lane;
         const bool valid = (t + 1) * (long long)kTile <= b;
@@ -151,6 +207,20 @@ __device__ __forceinline__ bool step_right(const float* __restrict__ g, const fl
     }
     const long long tile_hi = (cur / kTile + 1) * kTile;
     const long long hi = tile_hi < b ? tile_hi : b;
+    if (sp.stats32 != nullptr && (cur & 31) == 0 && cur + 32 <= hi) {
+        const long long r = (cur >> 5) + lane;
+        const bool valid = (r + 1) * 32 <= hi;
+        float2 st = make_float2(FLT_MAX, -FLT_MAX);
+        if (valid) st = sp.stats32[r];
+        const unsigned long long blocked = __ballot(valid && st.y > h);
+        const int nvalid = __popcll(__ballot(valid));
+        const int nskip = blocked ? (__ffsll((long long)blocked) - 1) : nvalid;
+        if (nskip > 0) {
+            vmin = fminf(vmin, wave_min(lane < nskip ? st.x : FLT_MAX));
+            cur += (long long)nskip * 32;
+            return false;
+        }
+    }
     const long long idx = cur + lane;
     const bool valid = idx < hi;
     const float v = valid ? score_for_min(g, sp, idx) : 0.0f;
