@@ -63,5 +63,33 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+CLI = os.path.join(HERE, "bin", "audiomatch")
+HOST = os.path.join(HERE, "host")
+
+
+def build_cli(force: bool = False) -> str:
+    """The C++ host CLI (matcher::run, src/matcher/mod.rs:17-104) linked against the library."""
+    lib = build_library()
+    srcs = [os.path.join(HOST, "audiomatch_cli.cpp"), os.path.join(HOST, "am_host.hpp")]
+    if not force and not _stale(CLI, srcs + [lib]):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-x", "c++", srcs[0], "-o", CLI,
+           f"-L{HERE}", "-laudiomatch_amd", "-Wl,-rpath,$ORIGIN/.."]
+    subprocess.check_call(cmd)
+    return CLI
+
+
+def build_selftest() -> str:
+    """CPU-only self test of the host-side rows (g++ only)."""
+    out = os.path.join(OBJ, "am_host_selftest")
+    os.makedirs(OBJ, exist_ok=True)
+    src = os.path.join(HOST, "selftest.cpp")
+    if _stale(out, [src, os.path.join(HOST, "am_host.hpp")]):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(HERE, "..", "include"), "-o", out, src])
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv))

@@ -42,6 +42,10 @@ static int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #call);    \
     } while (0)
 
+// progress hook (audio_matcher.rs:102-117, 129)
+static am_progress_fn g_progress_fn = nullptr;
+static void* g_progress_user = nullptr;
+
 // tuning knobs
 static long long g_opt_log_n = 0;          // 0 = auto
 static long long g_opt_pairs_per_group = 64;
@@ -468,6 +472,7 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
+        if (g_progress_fn) g_progress_fn(g_progress_user, k, 0, (size_t)ns);
         const long long out_count = (long long)(lens[k] - s + 1);
         if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
                                   &scan))) return rc;
@@ -517,6 +522,7 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
             }
         }
         rc = merge_peaks(all, p, out ? out + k * cap_per_hay : nullptr, cap_per_hay, &n_out[k]);
+        if (g_progress_fn) g_progress_fn(g_progress_user, k, 1, (size_t)(s1 - s0));
         if (rc == AM_ERR_CAPACITY) worst = rc;
         else if (rc) return rc;
     }
@@ -825,6 +831,12 @@ int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     AM_HIP(launch_axpy(c->stream, d_dst, d_src, (long long)n, gain));
     AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_set_progress_callback(am_progress_fn fn, void* user) {
+    g_progress_fn = fn;
+    g_progress_user = user;
     return AM_OK;
 }
 

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "am_synth_uniform_device": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.c_size_t, C.c_float]),
     "am_axpy_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "am_set_progress_callback": (C.c_int, [C.c_void_p, C.c_void_p]),
     "am_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "am_profile_reset": (C.c_int, [C.c_int]),
     "am_profile_query": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -325,6 +326,23 @@ def calc_chunks(sr: int, m_samples, algo_with_sample: HipConvolve, scale: bool, 
     """audio_matcher.rs:88-141 on the GPU: returns peaks sorted by position.start."""
     params = config.params(sr, Scale.LIB if scale else Scale.NONE)
     return algo_with_sample.match(m_samples, params)
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t)
+_progress_keepalive = None
+
+
+def set_progress_callback(fn):
+    """fn(haystack_index, stage, n_chunks): stage 0 = queued, 1 = finished
+    (the f1/f2 callbacks of audio_matcher.rs:102-117, 129); None clears it."""
+    global _progress_keepalive
+    if fn is None:
+        _progress_keepalive = None
+        _check(lib().am_set_progress_callback(None, None))
+        return
+    cb = PROGRESS_FN(lambda user, k, stage, n: fn(int(k), int(stage), int(n)))
+    _progress_keepalive = cb
+    _check(lib().am_set_progress_callback(C.cast(cb, C.c_void_p), None))
 
 
 class Profile:

@@ -151,6 +151,15 @@ int am_synth_uniform_device(int device, float* d_out, uint32_t seed, uint32_t st
 /* d_dst[i] += gain * d_src[i]  (plants a needle into a haystack) */
 int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float gain);
 
+/* ---- progress hook ---------------------------------------------------------- */
+/* The two-stage progress callbacks of calc_chunks (audio_matcher.rs:102-117, 129:
+ * f1 when a chunk is picked up, f2 when it is done).  All chunks of a haystack
+ * run in one set of launches here, so the hook fires per haystack: stage 0 with
+ * its chunk count when it is queued, stage 1 when its peaks are back on the host.
+ * Process-wide; pass NULL to clear. */
+typedef void (*am_progress_fn)(void* user, size_t haystack_index, int stage, size_t n_chunks);
+int am_set_progress_callback(am_progress_fn fn, void* user);
+
 /* ---- measurement hooks ---------------------------------------------------- */
 /* When enabled every kernel launch of the pipeline on `device` is bracketed by
  * HIP events on the stream it is launched on.  am_profile_query returns the

@@ -97,3 +97,13 @@ def test_cpp_host_mirror_compiles():
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c++", "-"],
                    input=src, text=True, check=True)
     assert os.path.exists(hpp)
+
+
+def test_host_rows_selftest():
+    """parse_duration doctest vectors (src/args.rs:66-78), Arguments defaults, print_offsets and
+    timelabel_from_peaks formatting of the C++ host code (no GPU needed)."""
+    import build as am_build
+    exe = am_build.build_selftest()
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "selftest ok" in out.stdout
