@@ -277,9 +277,9 @@ struct ScanRequest {
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
-static int run_correlation(am_needle* h, const float* d_src, long long src_len, long long lead,
+static int run_correlation(am_needle* h, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
-                           ScanRequest* scan_req = nullptr) {
+                           ScanRequest* scan_req = nullptr, int src_kind = 0) {
     Ctx* c = h->ctx;
     int logN = 0;
     int rc = pick_log_n(h->n, out_count, &logN);
@@ -314,7 +314,7 @@ static int run_correlation(am_needle* h, const float* d_src, long long src_len, 
         }
     }
     Job job{};
-    job.src = d_src; job.src_len = src_len; job.lead = lead;
+    job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
     for (long long first = 0; first < npairs; first += ppg) {
         const int np = (int)std::min(ppg, npairs - first);
@@ -427,8 +427,8 @@ static int merge_peaks(std::vector<am_peak>& all, const am_match_params* p, am_p
 // the per-file loop of matcher::run (matcher/mod.rs:42-87).  Everything is
 // queued on the context's stream without host synchronisation; one small
 // device-to-host copy of the per-chunk headers ends the batch.
-static int match_many(am_needle* h, const float* const* d_hays, const size_t* lens, size_t n_hay,
-                      const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+static int match_many(am_needle* h, const void* const* d_hays, const size_t* lens, size_t n_hay,
+                      const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0) {
     Ctx* c = h->ctx;
     const size_t s = h->n;
     if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
@@ -475,7 +475,7 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
         if (g_progress_fn) g_progress_fn(g_progress_user, k, 0, (size_t)ns);
         const long long out_count = (long long)(lens[k] - s + 1);
         if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
-                                  &scan))) return rc;
+                                  &scan, src_kind))) return rc;
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, seg_off[k], ns, p->min_prominence,
                               (long long)p->min_distance, &scan))) return rc;
     }
@@ -505,7 +505,7 @@ static int match_many(am_needle* h, const float* const* d_hays, const size_t* le
             ScanRequest full = scan;
             full.theta = -FLT_MAX;
             if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
-                                      &full))) return rc;
+                                      &full, src_kind))) return rc;
             if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, s0, s1 - s0, p->min_prominence,
                                   (long long)p->min_distance, &full))) return rc;
             AM_HIP(hipMemcpyAsync(h_hdr + s0, (SegHeader*)c->hdr.p + s0, sizeof(SegHeader) * (s1 - s0),
@@ -694,7 +694,8 @@ int am_match_device(const am_needle* hc, const float* d_haystack, size_t len,
     if (!d_haystack || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
     if (len == 0) { *n_out = 0; return AM_OK; }
     std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
-    return match_many(h, &d_haystack, &len, 1, p, out, cap, n_out);
+    const void* src = d_haystack;
+    return match_many(h, &src, &len, 1, p, out, cap, n_out);
 }
 
 int am_match(const am_needle* hc, const float* haystack, size_t len,
@@ -708,7 +709,7 @@ int am_match(const am_needle* hc, const float* haystack, size_t len,
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(len * sizeof(float)))) return rc;
     AM_HIP(hipMemcpy(c->io_in.p, haystack, len * sizeof(float), hipMemcpyHostToDevice));
-    const float* d_in = (const float*)c->io_in.p;
+    const void* d_in = c->io_in.p;
     return match_many(h, &d_in, &len, 1, p, out, cap, n_out);
 }
 
@@ -721,7 +722,64 @@ int am_match_batch_device(const am_needle* hc, const float* const* d_haystacks, 
     if (!d_haystacks || !lens || !p || !n_out || (!out && cap_per_hay)) return fail(AM_ERR_INVALID_ARG, "null pointer");
     std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
     if (n_hay == 0) return AM_OK;
-    return match_many(h, d_haystacks, lens, n_hay, p, out, cap_per_hay, n_out);
+    return match_many(h, reinterpret_cast<const void* const*>(d_haystacks), lens, n_hay, p, out, cap_per_hay, n_out);
+}
+
+// ---- the same three entry points on interleaved i16 stereo PCM: the down-mix of
+// mp3_reader.rs:28-37 happens inside K1's loads, so the haystack is read once ----
+int am_match_pcm16_device(const am_needle* hc, const int16_t* d_interleaved, size_t frames,
+                          const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!d_interleaved || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (frames == 0) { *n_out = 0; return AM_OK; }
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    const void* src = d_interleaved;
+    return match_many(h, &src, &frames, 1, p, out, cap, n_out, 1);
+}
+
+int am_match_pcm16(const am_needle* hc, const int16_t* interleaved, size_t frames,
+                   const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!interleaved || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (frames == 0) { *n_out = 0; return AM_OK; }
+    Ctx* c = h->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if ((rc = c->io_in.ensure(frames * 2 * sizeof(int16_t)))) return rc;
+    AM_HIP(hipMemcpy(c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    const void* d_in = c->io_in.p;
+    return match_many(h, &d_in, &frames, 1, p, out, cap, n_out, 1);
+}
+
+int am_match_pcm16_batch_device(const am_needle* hc, const int16_t* const* d_interleaved, const size_t* frames,
+                                size_t n_hay, const am_match_params* p,
+                                am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!d_interleaved || !frames || !p || !n_out || (!out && cap_per_hay)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    if (n_hay == 0) return AM_OK;
+    return match_many(h, reinterpret_cast<const void* const*>(d_interleaved), frames, n_hay, p, out, cap_per_hay, n_out, 1);
+}
+
+int am_needle_create_pcm16(int device, const int16_t* interleaved, size_t frames, am_needle** out) {
+    if (!interleaved || !out || frames == 0) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if ((rc = c->io_in.ensure(frames * 2 * sizeof(int16_t)))) return rc;
+    AM_HIP(hipMemcpy(c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    float* d = nullptr;
+    AM_HIP(hipMalloc((void**)&d, frames * sizeof(float)));
+    hipError_t e = launch_pcm_downmix(c->stream, (const int16_t*)c->io_in.p, (long long)frames, d);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "needle down-mix"); }
+    return create_needle_common(c, d, frames, out);
 }
 
 int am_find_peaks(int device, const float* scores, size_t n, float min_prominence,

@@ -152,16 +152,36 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
 constexpr int kR16LogN1 = 8, kR16LogN2 = 13;
 constexpr int kN2 = 1 << kR16LogN2;
 
-__device__ __forceinline__ float2 load2_padded(const float* __restrict__ src, long long i, long long len) {
+// Input samples: KIND 0 = f32 mono, KIND 1 = interleaved i16 stereo frames,
+// down-mixed on the fly exactly as mp3_reader.rs:12, 28-37:
+// (l as f32 + r as f32) * 0.5 * (1 / 65535), every step rounded to f32.
+__device__ __forceinline__ float downmix_s16(short2 lr) {
+    return __fmul_rn(__fmul_rn(__fadd_rn((float)lr.x, (float)lr.y), 0.5f), 1.0f / 65535.0f);
+}
+template <int KIND>
+__device__ __forceinline__ float load_sample(const void* __restrict__ src, long long i) {
+    if (KIND == 0) return static_cast<const float*>(src)[i];
+    return downmix_s16(static_cast<const short2*>(src)[i]);
+}
+// two consecutive samples from an 8-byte aligned position
+template <int KIND>
+__device__ __forceinline__ float2 load_sample2(const void* __restrict__ src, long long i) {
+    if (KIND == 0) return *reinterpret_cast<const float2*>(static_cast<const float*>(src) + i);
+    const int2 raw = *reinterpret_cast<const int2*>(static_cast<const short2*>(src) + i);
+    return make_float2(downmix_s16(__builtin_bit_cast(short2, raw.x)), downmix_s16(__builtin_bit_cast(short2, raw.y)));
+}
+template <int KIND>
+__device__ __forceinline__ float2 load2_padded(const void* __restrict__ src, long long i, long long len) {
     float2 v;
-    v.x = (i >= 0 && i < len) ? src[i] : 0.0f;
-    v.y = (i + 1 >= 0 && i + 1 < len) ? src[i + 1] : 0.0f;
+    v.x = (i >= 0 && i < len) ? load_sample<KIND>(src, i) : 0.0f;
+    v.y = (i + 1 >= 0 && i + 1 < len) ? load_sample<KIND>(src, i + 1) : 0.0f;
     return v;
 }
 
 // K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
 // FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
 // holds frequency k1 in natural order.
+template <int KIND>
 __global__ void __launch_bounds__(256, 3)
 k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
@@ -180,12 +200,10 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     // pass 1 ownership: b = hi (n1 = a*16 + b), columns 2cp, 2cp+1
     const long long col = n2_0 + 2 * cp;
     if (fast) {
-        const float2* __restrict__ sa = reinterpret_cast<const float2*>(job.src + baseA + col);
-        const float2* __restrict__ sb = reinterpret_cast<const float2*>(job.src + baseB + col);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const size_t off = (size_t)(a * 16 + hi) * (kN2 / 2);
-            const float2 va = sa[off], vb = sb[off];
+            const long long off = (long long)(a * 16 + hi) * kN2 + col;
+            const float2 va = load_sample2<KIND>(job.src, baseA + off), vb = load_sample2<KIND>(job.src, baseB + off);
             x0[a] = make_float2(va.x, vb.x);
             x1[a] = make_float2(va.y, vb.y);
         }
@@ -193,8 +211,8 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             const long long n = (long long)(a * 16 + hi) * kN2 + col;
-            const float2 va = load2_padded(job.src, baseA + n, job.src_len);
-            const float2 vb = validB ? load2_padded(job.src, baseB + n, job.src_len) : make_float2(0.f, 0.f);
+            const float2 va = load2_padded<KIND>(job.src, baseA + n, job.src_len);
+            const float2 vb = validB ? load2_padded<KIND>(job.src, baseB + n, job.src_len) : make_float2(0.f, 0.f);
             x0[a] = make_float2(va.x, vb.x);
             x1[a] = make_float2(va.y, vb.y);
         }
@@ -804,12 +822,13 @@ __device__ void lds_fft_inv(float2* s, int logL, const float2* __restrict__ tw, 
     }
 }
 
-__device__ __forceinline__ float load_padded(const float* __restrict__ src, long long i, long long len) {
-    return (i >= 0 && i < len) ? src[i] : 0.0f;
+template <int KIND>
+__device__ __forceinline__ float load_padded(const void* __restrict__ src, long long i, long long len) {
+    return (i >= 0 && i < len) ? load_sample<KIND>(src, i) : 0.0f;
 }
 
 // K1 generic: row p of the work matrix holds frequency k1 = bitrev(p).
-template <int BL>
+template <int BL, int KIND>
 __global__ void __launch_bounds__(kFftThreads)
 k1_cols_fwd_gen(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float2 s[];
@@ -825,8 +844,8 @@ k1_cols_fwd_gen(Job job, float2* __restrict__ work, PlanDev pl) {
     for (int idx = tid; idx < total; idx += nthr) {
         const int r = idx >> BL, c = idx & ((1 << BL) - 1);
         const long long n = (long long)r * N2 + n2_0 + c;
-        const float a = load_padded(job.src, baseA + n, job.src_len);
-        const float b = validB ? load_padded(job.src, baseB + n, job.src_len) : 0.0f;
+        const float a = load_padded<KIND>(job.src, baseA + n, job.src_len);
+        const float b = validB ? load_padded<KIND>(job.src, baseB + n, job.src_len) : 0.0f;
         s[idx] = make_float2(a, b);
     }
     __syncthreads();
@@ -916,11 +935,13 @@ hipError_t fft_kernels_init() {
 #define AM_SET_LDS(fn, bytes)                                                                     \
     e = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
     if (e != hipSuccess) return e;
-    AM_SET_LDS(k1_cols_fwd_gen<kColsLog>, kMaxLds)
+    AM_SET_LDS((k1_cols_fwd_gen<kColsLog, 0>), kMaxLds)
+    AM_SET_LDS((k1_cols_fwd_gen<kColsLog, 1>), kMaxLds)
     AM_SET_LDS(k3_cols_inv_gen<kColsLog>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<false>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<true>, kMaxLds)
-    AM_SET_LDS(k1_cols_fwd_r16, kR16LdsK1)
+    AM_SET_LDS(k1_cols_fwd_r16<0>, kR16LdsK1)
+    AM_SET_LDS(k1_cols_fwd_r16<1>, kR16LdsK1)
     AM_SET_LDS(k3_cols_inv_r16, kR16LdsK3)
     AM_SET_LDS(k2_rows_r16<false>, kR16Lds)
     AM_SET_LDS(k2_rows_r16<true>, kR16Lds)
@@ -932,11 +953,14 @@ hipError_t fft_kernels_init() {
 
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
+    const bool pcm = job.src_kind == 1;
     if (plan_is_r16(pl)) {
-        hipLaunchKernelGGL(k1_cols_fwd_r16, grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        if (pcm) hipLaunchKernelGGL(k1_cols_fwd_r16<1>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        else hipLaunchKernelGGL(k1_cols_fwd_r16<0>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
-        hipLaunchKernelGGL(k1_cols_fwd_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl);
+        if (pcm) hipLaunchKernelGGL((k1_cols_fwd_gen<kColsLog, 1>), grid, dim3(kFftThreads), lds, st, job, work, pl);
+        else hipLaunchKernelGGL((k1_cols_fwd_gen<kColsLog, 0>), grid, dim3(kFftThreads), lds, st, job, work, pl);
     }
     return hipGetLastError();
 }

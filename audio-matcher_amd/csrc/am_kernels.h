@@ -15,14 +15,15 @@ namespace am {
 // and yields scores [b*hop, b*hop + hop).  Two blocks are packed into one
 // complex transform (re = block 2g, im = block 2g+1).
 struct Job {
-    const float* src;     // device
-    long long src_len;
+    const void* src;      // device: f32 mono samples, or interleaved i16 stereo frames (src_kind 1)
+    long long src_len;    // samples / frames
     long long lead;       // virtual zeros in front of src[0]
     float* dst;           // device, out_count scores
     long long out_count;
     int hop;              // new scores per block (<= N - S + 1)
     int nblocks;          // ceil(out_count / hop)
     int first_pair;       // first pair handled by this launch (slot 0 of work)
+    int src_kind;         // 0 = f32 mono, 1 = i16 stereo (down-mixed in K1, mp3_reader.rs:28-37)
 };
 
 // Factorisation N = N1 * N2 of the complex transform and its twiddle tables.

@@ -82,6 +82,14 @@ _SIGNATURES = {
     "am_match_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                         C.c_size_t, C.POINTER(AmMatchParams), C.POINTER(AmPeak),
                                         C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_needle_create_pcm16": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "am_match_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AmMatchParams),
+                                 C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match_pcm16_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AmMatchParams),
+                                        C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match_pcm16_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                              C.c_size_t, C.POINTER(AmMatchParams), C.POINTER(AmPeak),
+                                              C.c_size_t, C.POINTER(C.c_size_t)]),
     "am_find_peaks": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_uint64,
                                 C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
     "am_pcm_s16_stereo_to_mono": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -265,6 +273,30 @@ class HipConvolve:
         _check(lib().am_needle_create_device(device, ptr, n, C.byref(self._h)))
         self.sample_len = int(n)
         return self
+
+    @classmethod
+    def from_pcm16(cls, interleaved, device: int = 0) -> "HipConvolve":
+        """Needle given as interleaved i16 stereo frames (down-mixed on the GPU)."""
+        a = np.ascontiguousarray(interleaved, dtype=np.int16)
+        self = cls.__new__(cls)
+        self.device = device
+        self._h = C.c_void_p()
+        _check(lib().am_needle_create_pcm16(device, a.ctypes.data, a.size // 2, C.byref(self._h)))
+        self.sample_len = int(a.size // 2)
+        return self
+
+    def match_pcm16(self, interleaved, params: AmMatchParams, cap: int = 4096):
+        a = np.ascontiguousarray(interleaved, dtype=np.int16)
+        buf = (AmPeak * cap)()
+        n = C.c_size_t(0)
+        _check(lib().am_match_pcm16(self._h, a.ctypes.data, a.size // 2, C.byref(params), buf, cap, C.byref(n)))
+        return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
+
+    def match_pcm16_device(self, ptr: int, frames: int, params: AmMatchParams, cap: int = 4096):
+        buf = (AmPeak * cap)()
+        n = C.c_size_t(0)
+        _check(lib().am_match_pcm16_device(self._h, ptr, frames, C.byref(params), buf, cap, C.byref(n)))
+        return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
 
     def close(self):
         if getattr(self, "_h", None):

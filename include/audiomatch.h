@@ -125,6 +125,19 @@ int am_match_batch_device(const am_needle* h, const float* const* d_haystacks, c
                           size_t n_hay, const am_match_params* p,
                           am_peak* out, size_t cap_per_hay, size_t* n_out);
 
+/* The same matcher on interleaved 16-bit stereo PCM, the sample format the
+ * reference decodes to (mp3_reader.rs:26 asserts two channels): the down-mix
+ * mono = (l as f32 + r as f32) * 0.5 * (1/65535) (mp3_reader.rs:12, 28-37) is
+ * fused into the first kernel's loads, bit-exact, so PCM is read once. */
+int am_needle_create_pcm16(int device, const int16_t* interleaved, size_t frames, am_needle** out);
+int am_match_pcm16(const am_needle* h, const int16_t* interleaved, size_t frames,
+                   const am_match_params* p, am_peak* out, size_t cap, size_t* n_out);
+int am_match_pcm16_device(const am_needle* h, const int16_t* d_interleaved, size_t frames,
+                          const am_match_params* p, am_peak* out, size_t cap, size_t* n_out);
+int am_match_pcm16_batch_device(const am_needle* h, const int16_t* const* d_interleaved, const size_t* frames,
+                                size_t n_hay, const am_match_params* p,
+                                am_peak* out, size_t cap_per_hay, size_t* n_out);
+
 /* find_peaks(y_data, sr, PeakConfig) (audio_matcher.rs:221-230) =
  * PeakFinder::new(y).with_min_prominence(p).with_min_distance(d).find_peaks()
  * on one host score array; peaks come back by descending height. */

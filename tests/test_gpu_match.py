@@ -181,3 +181,53 @@ def test_peak_in_chunk_edge_run_sparse(gpu, oracle):
         got = algo.match(hay, p)
         exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
         assert_same(got, exp)
+
+
+def test_pcm16_stereo_ingest_fused(gpu, oracle):
+    """BASELINE config 5's input format: 48 kHz interleaved i16 stereo.  The
+    down-mix fused into K1 must give exactly what the separate down-mix kernel +
+    f32 path gives (same f32 samples -> identical arithmetic) and the oracle's
+    offsets."""
+    sr = 48000
+    rng = np.random.default_rng(12)
+    s, h = 10 * sr, 200 * sr
+    needle_lr = rng.integers(-9000, 9000, size=2 * s).astype(np.int16)
+    hay_lr = rng.integers(-9000, 9000, size=2 * h).astype(np.int32)
+    for t in (17.0, 71.3, 140.0):
+        off = int(t * sr)
+        hay_lr[2 * off:2 * (off + s)] += needle_lr
+    hay_lr = np.clip(hay_lr, -32768, 32767).astype(np.int16)
+    needle = oracle.pcm_s16_stereo_to_mono(needle_lr)
+    hay = oracle.pcm_s16_stereo_to_mono(hay_lr)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=30.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+    assert [e[0] for e in exp] == [int(17.0 * sr), int(71.3 * sr), 140 * sr]
+    a_pcm = gpu.HipConvolve.from_pcm16(needle_lr)
+    a_f32 = gpu.HipConvolve(needle)
+    assert a_pcm.inverse_sample_auto_correlation() == a_f32.inverse_sample_auto_correlation()
+    for _ in range(2):                       # second round exercises the sparse-score path
+        got_pcm = a_pcm.match_pcm16(hay_lr, p)
+        got_f32 = a_f32.match(hay, p)
+        assert_same(got_pcm, exp)
+        assert [(g.start, g.end, g.height, g.prominence) for g in got_pcm] == \
+               [(g.start, g.end, g.height, g.prominence) for g in got_f32]
+
+
+def test_pcm16_small_generic_plan(gpu, oracle):
+    """i16 ingest through the generic kernels (small transform) incl. odd offsets."""
+    sr = 8000
+    rng = np.random.default_rng(3)
+    s, h = 1500, 30001
+    needle_lr = rng.integers(-20000, 20000, size=2 * s).astype(np.int16)
+    hay_lr = rng.integers(-20000, 20000, size=2 * h).astype(np.int32)
+    hay_lr[2 * 7777:2 * (7777 + s)] += needle_lr
+    hay_lr = np.clip(hay_lr, -32768, 32767).astype(np.int16)
+    needle = oracle.pcm_s16_stereo_to_mono(needle_lr)
+    hay = oracle.pcm_s16_stereo_to_mono(hay_lr)
+    cfg = gpu.Config(chunk_size_s=1.0, overlap_length_s=s / sr, distance_s=2.0, prominence=0.4)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.4, p.min_distance, 2.0)
+    got = gpu.HipConvolve.from_pcm16(needle_lr).match_pcm16(hay_lr, p)
+    assert [e[0] for e in exp] == [7777]
+    assert_same(got, exp)
