@@ -98,7 +98,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, scores, stats, stats32, wflags, segs, hdr, peaks, counts, io_in, io_out, sum;
+    DevBuf work, work2, scores, stats, stats32, wflags, segs, hdr, peaks, counts, io_in, io_out, sum;
     HostBuf pinned;
     // profiling
     bool prof = false;
@@ -371,7 +371,8 @@ static bool is_overshadowed(const am_peak& element, const am_peak* other, uint32
 // resident score array; segment descriptors and result headers live at
 // [seg_off, seg_off + nsegs) of the context's segment / header buffers.
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
-                       float min_prom, long long min_dist, const ScanRequest* scan) {
+                       float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off = -1) {
+    if (hdr_off < 0) hdr_off = seg_off;
     const float2* d_stats32 = (scan && scan->fused) ? scan->sparse.stats32 : nullptr;
     const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
@@ -387,7 +388,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         ProfScope ps(c, KN_PEAKS);
         AM_HIP(launch_peaks(c->stream, d_scores, n_scores, (const float2*)c->stats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p + seg_off, sp));
+                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p + hdr_off, sp));
     }
     return AM_OK;
 }
@@ -523,6 +524,116 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         }
         rc = merge_peaks(all, p, out ? out + k * cap_per_hay : nullptr, cap_per_hay, &n_out[k]);
         if (g_progress_fn) g_progress_fn(g_progress_user, k, 1, (size_t)(s1 - s0));
+        if (rc == AM_ERR_CAPACITY) worst = rc;
+        else if (rc) return rc;
+    }
+    return worst;
+}
+
+
+// BASELINE config 4: several needles against one resident haystack.  The
+// haystack's forward column pass (K1) runs once; every needle then gets its own
+// K2 (row transforms + multiply with that needle's spectrum, written to a second
+// work matrix), K3 (fused scan) and peak pick.  Needles must share one length so
+// that they share the block layout.
+static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, size_t len, int src_kind,
+                       const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out) {
+    am_needle* h0 = needles[0];
+    Ctx* c = h0->ctx;
+    const size_t s = h0->n;
+    for (size_t k = 0; k < nn; ++k) {
+        n_out[k] = 0;
+        if (!needles[k] || needles[k]->ctx != c) return fail(AM_ERR_INVALID_ARG, "needles must live on one device");
+        if (needles[k]->n != s) return fail(AM_ERR_INVALID_ARG, "am_match_multi: needles must have equal length");
+    }
+    if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
+    if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
+        return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB");
+    if (len < s) return AM_OK;
+    const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
+    std::vector<Segment> segs;
+    make_segments(len, s, p, segs);
+    const int nsegs = (int)segs.size();
+    if (nsegs == 0) return AM_OK;
+    const long long out_count = (long long)(len - s + 1);
+    int rc, logN = 0;
+    if ((rc = pick_log_n(s, out_count, &logN))) return rc;
+    const Plan* pl = nullptr;
+    if ((rc = get_plan(c, logN, &pl))) return rc;
+    const long long N = 1ll << logN;
+    long long hop = N - (long long)s + 1;
+    if (hop >= 8 * kTile) hop = (hop / kTile) * kTile;
+    const long long nblocks = (out_count + hop - 1) / hop;
+    const long long npairs = (nblocks + 1) / 2;
+    std::vector<const float2*> hcs(nn);
+    for (size_t k = 0; k < nn; ++k)
+        if ((rc = needle_spectrum(needles[k], pl, &hcs[k]))) return rc;   // may use c->work: before it is filled
+    if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
+    if ((rc = c->work2.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
+    if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
+    const size_t seg_bytes = sizeof(Segment) * nsegs, hdr_bytes = sizeof(SegHeader) * nsegs * nn;
+    if ((rc = c->segs.ensure(seg_bytes))) return rc;
+    if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
+    if ((rc = c->peaks.ensure(sizeof(am_peak) * (size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    if ((rc = c->pinned.ensure(seg_bytes + hdr_bytes + 64))) return rc;
+    memcpy(c->pinned.p, segs.data(), seg_bytes);
+    SegHeader* h_hdr = reinterpret_cast<SegHeader*>(static_cast<char*>(c->pinned.p) + ((seg_bytes + 63) & ~(size_t)63));
+    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, seg_bytes, hipMemcpyHostToDevice, c->stream));
+    const bool fused = plan_is_r16(pl->dev) && (hop % kTile) == 0;
+    if (fused) {
+        if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
+        if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
+    }
+    Job job{};
+    job.src = d_hay; job.src_len = (long long)len; job.lead = 0; job.src_kind = src_kind;
+    job.dst = (float*)c->scores.p; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
+    job.first_pair = 0;
+    { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)npairs, (float2*)c->work.p, pl->dev)); }
+    for (size_t k = 0; k < nn; ++k) {
+        am_needle* h = needles[k];
+        ScanRequest scan{};
+        scan.theta = (h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+        scan.seg_c = (long long)p->chunk;
+        scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
+        scan.fused = fused;
+        scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+        ScanCfg cfg{};
+        if (fused) {
+            cfg.stats32 = (float2*)c->stats32.p; cfg.wflags = (unsigned char*)c->wflags.p; cfg.theta = scan.theta;
+            cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
+            scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+        }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, (const float2*)c->work2.p, pl->dev,
+                                                  scale_factor(h, p->scale, 1), cfg)); }
+        if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
+                              (long long)p->min_distance, &scan, (int)(k * nsegs)))) return rc;
+    }
+    AM_HIP(hipMemcpyAsync(h_hdr, c->hdr.p, hdr_bytes, hipMemcpyDeviceToHost, c->stream));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    int worst = AM_OK;
+    std::vector<am_peak> all;
+    for (size_t k = 0; k < nn; ++k) {
+        am_needle* h = needles[k];
+        const SegHeader* hd = h_hdr + k * nsegs;
+        bool big = false;
+        for (int i = 0; i < nsegs; ++i) {
+            if (hd[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+            if (hd[i].n > kInlinePeaks || (hd[i].overflow & 2)) big = true;
+            if (!h->have_min[sm] || hd[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = hd[i].seg_min; h->have_min[sm] = true; }
+        }
+        am_peak* dst = out ? out + k * cap_per_needle : nullptr;
+        if (big) {   // rare: redo this needle alone through the single-needle path (writes every score)
+            const bool keep = h->have_min[sm];
+            h->have_min[sm] = false;             // forces theta = -inf
+            rc = match_many(h, &d_hay, &len, 1, p, dst, cap_per_needle, &n_out[k], src_kind);
+            h->have_min[sm] = h->have_min[sm] || keep;
+        } else {
+            all.clear();
+            for (int i = 0; i < nsegs; ++i)
+                for (int j = 0; j < hd[i].n; ++j) all.push_back(hd[i].first[j]);
+            rc = merge_peaks(all, p, dst, cap_per_needle, &n_out[k]);
+        }
         if (rc == AM_ERR_CAPACITY) worst = rc;
         else if (rc) return rc;
     }
@@ -723,6 +834,19 @@ int am_match_batch_device(const am_needle* hc, const float* const* d_haystacks, 
     std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
     if (n_hay == 0) return AM_OK;
     return match_many(h, reinterpret_cast<const void* const*>(d_haystacks), lens, n_hay, p, out, cap_per_hay, n_out);
+}
+
+int am_match_multi_device(const am_needle* const* needles, size_t n_needles, const float* d_haystack, size_t len,
+                          const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out) {
+    if (!needles || n_needles == 0 || !d_haystack || !p || !n_out || (!out && cap_per_needle))
+        return fail(AM_ERR_INVALID_ARG, "null pointer");
+    for (size_t k = 0; k < n_needles; ++k)
+        if (!needles[k] || !needles[k]->ctx) return fail(AM_ERR_INVALID_ARG, "null needle handle");
+    am_needle* h0 = const_cast<am_needle*>(needles[0]);
+    int rc = check_needle(h0);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(h0->ctx->mu);
+    return match_multi(const_cast<am_needle* const*>(needles), n_needles, d_haystack, len, 0, p, out, cap_per_needle, n_out);
 }
 
 // ---- the same three entry points on interleaved i16 stereo PCM: the down-mix of

@@ -394,9 +394,12 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     twiddle_nat<16, true>(x1, wj1);
     dif<16, true>(x0);
     dif<16, true>(x1);
+    // in place, or into a second work matrix (hc_out doubles as that destination
+    // when several needles share one forward pass, am_match_multi_device)
+    const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(hc_out + row_off, kN2 * 8) : rrow;
 #pragma unroll
     for (int a = 0; a < 16; ++a)
-        buf_store4(rrow, voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+        buf_store4(rdst, voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
                                                      x1[brev<16>(a)].x, x1[brev<16>(a)].y));
 }
 
@@ -524,8 +527,9 @@ k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* _
     for (int ap = 0; ap < 16; ++ap) x[ap] = lds2[ap * 512 + t];
     twiddle_nat<16, true>(x, wj);
     dif<16, true>(x);
+    const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(hc_out + row_off, kN2 * 8) : rrow;
 #pragma unroll
-    for (int a = 0; a < 16; ++a) buf_store2(rrow, voff, a * 4096, x[brev<16>(a)]);
+    for (int a = 0; a < 16; ++a) buf_store2(rdst, voff, a * 4096, x[brev<16>(a)]);
 }
 
 // Reduction across the 16 lanes of a group of 16 per-lane values v[0..15]
@@ -883,7 +887,8 @@ k2_rows_gen(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     for (int q = tid; q < N2; q += nthr) s[q] = cmul(s[q], hc[hoff + q]);
     __syncthreads();
     lds_fft_inv<0>(s, pl.logN2, pl.tw2, tid, nthr);
-    for (int n2 = tid; n2 < N2; n2 += nthr) row[n2] = s[n2];
+    float2* orow = hc_out ? hc_out + ((size_t)blockIdx.y << pl.logN) + (size_t)p * N2 : row;
+    for (int n2 = tid; n2 < N2; n2 += nthr) orow[n2] = s[n2];
 }
 
 template <int BL>
@@ -965,17 +970,17 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
     return hipGetLastError();
 }
 
-hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl) {
+hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst) {
     const dim3 grid(1u << pl.logN1, npairs);
     if (plan_is_r16(pl) && g_k2_variant == 1) {
         hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << pl.logN1), dim3(512), kR16Lds, st, work, hc,
-                           (float2*)nullptr, pl, (unsigned)npairs);
+                           dst, pl, (unsigned)npairs);
     } else if (plan_is_r16(pl)) {
         hipLaunchKernelGGL(k2_rows_r16<false>, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
-                           (float2*)nullptr, pl, (unsigned)npairs);
+                           dst, pl, (unsigned)npairs);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
-        hipLaunchKernelGGL(k2_rows_gen<false>, grid, dim3(kFftThreads), lds, st, work, hc, (float2*)nullptr, pl);
+        hipLaunchKernelGGL(k2_rows_gen<false>, grid, dim3(kFftThreads), lds, st, work, hc, dst, pl);
     }
     return hipGetLastError();
 }

@@ -46,7 +46,8 @@ struct Segment {
 };
 
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl);
-hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl);
+// dst == nullptr: in place; otherwise the result goes to a second work matrix
+hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
 // The score scan fused into K3 (r16 plan only).  stats32 == nullptr disables it
 // (plain correlation: every score is written).

@@ -82,6 +82,9 @@ _SIGNATURES = {
     "am_match_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                         C.c_size_t, C.POINTER(AmMatchParams), C.POINTER(AmPeak),
                                         C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match_multi_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                        C.POINTER(C.c_size_t)]),
     "am_needle_create_pcm16": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "am_match_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AmMatchParams),
                                  C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -352,6 +355,17 @@ class HipConvolve:
             sl = buf[i * cap_per_hay: i * cap_per_hay + counts[i]]
             out.append([Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in sl])
         return out
+
+
+def match_multi_device(algos, ptr: int, length: int, params: AmMatchParams, cap_per_needle: int = 256):
+    """Several equal-length needles against one resident haystack (shared forward pass)."""
+    k = len(algos)
+    handles = (C.c_void_p * k)(*[a._h for a in algos])
+    buf = (AmPeak * (cap_per_needle * k))()
+    counts = (C.c_size_t * k)()
+    _check(lib().am_match_multi_device(handles, k, ptr, length, C.byref(params), buf, cap_per_needle, counts))
+    return [[Peak(int(b.start), int(b.end), float(b.height), float(b.prominence))
+             for b in buf[i * cap_per_needle: i * cap_per_needle + counts[i]]] for i in range(k)]
 
 
 def calc_chunks(sr: int, m_samples, algo_with_sample: HipConvolve, scale: bool, config: Config):

@@ -125,6 +125,14 @@ int am_match_batch_device(const am_needle* h, const float* const* d_haystacks, c
                           size_t n_hay, const am_match_params* p,
                           am_peak* out, size_t cap_per_hay, size_t* n_out);
 
+/* Several needles (equal length, same device) against one resident haystack
+ * (BASELINE config 4): the haystack's forward column pass is computed once and
+ * shared; out holds cap_per_needle slots per needle, n_out[k] the count for
+ * needle k.  The reference has no such entry point (one snippet per run,
+ * matcher/mod.rs:29-34); results equal n_needles separate am_match_device calls. */
+int am_match_multi_device(const am_needle* const* needles, size_t n_needles, const float* d_haystack, size_t len,
+                          const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out);
+
 /* The same matcher on interleaved 16-bit stereo PCM, the sample format the
  * reference decodes to (mp3_reader.rs:26 asserts two channels): the down-mix
  * mono = (l as f32 + r as f32) * 0.5 * (1/65535) (mp3_reader.rs:12, 28-37) is

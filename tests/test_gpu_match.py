@@ -231,3 +231,35 @@ def test_pcm16_small_generic_plan(gpu, oracle):
     got = gpu.HipConvolve.from_pcm16(needle_lr).match_pcm16(hay_lr, p)
     assert [e[0] for e in exp] == [7777]
     assert_same(got, exp)
+
+
+def test_multi_needle_shared_forward_pass(gpu, oracle):
+    """BASELINE config 4 shape (several needles, one haystack): equals separate
+    single-needle calls and the oracle, on both calls (dense and sparse scores)."""
+    sr = 44100
+    s, h = 5 * sr, 160 * sr
+    needles = [oracle.synth_uniform(21, 100 + k, 0, s) for k in range(4)]
+    hay = oracle.synth_uniform(21, 1, 0, h)
+    plants = {0: [12.0, 100.0], 1: [45.5], 2: [], 3: [70.0, 120.25, 150.0]}
+    for k, ts in plants.items():
+        for t in ts:
+            off = int(t * sr)
+            hay[off:off + s] += needles[k]
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=5.0, distance_s=20.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algos = [gpu.HipConvolve(n) for n in needles]
+    buf = gpu.DeviceBuffer.from_numpy(0, hay)
+    exps = [oracle.calc_chunks(sr, hay, n, p.chunk, p.overlap, 0.13, p.min_distance, 20.0) for n in needles]
+    for k, ts in plants.items():
+        assert [e[0] for e in exps[k]] == [int(t * sr) for t in ts]
+    for _ in range(2):
+        res = gpu.match_multi_device(algos, buf.ptr, hay.size, p)
+        for got, exp in zip(res, exps):
+            assert_same(got, exp)
+    singles = [a.match_device(buf.ptr, hay.size, p) for a in algos]
+    res = gpu.match_multi_device(algos, buf.ptr, hay.size, p)
+    for got, one in zip(res, singles):
+        assert [(g.start, g.end, g.height, g.prominence) for g in got] == \
+               [(g.start, g.end, g.height, g.prominence) for g in one]
+    with pytest.raises(gpu.AudioMatchError):
+        gpu.match_multi_device([algos[0], gpu.HipConvolve(needles[1][:-1])], buf.ptr, hay.size, p)
