@@ -263,3 +263,74 @@ def test_multi_needle_shared_forward_pass(gpu, oracle):
                [(g.start, g.end, g.height, g.prominence) for g in one]
     with pytest.raises(gpu.AudioMatchError):
         gpu.match_multi_device([algos[0], gpu.HipConvolve(needles[1][:-1])], buf.ptr, hay.size, p)
+
+
+def test_handle_is_shareable_across_threads(gpu, oracle):
+    """The reference shares &algo across rayon workers (C: Sync, audio_matcher.rs:89,114-122):
+    concurrent calls on one handle, and on two handles, must stay correct."""
+    import threading
+    sr = 8000
+    needle, hay_a = synth_case(oracle, sr, 1.0, 40.0, [3.0, 33.0], seed=31, stream=1)
+    _, hay_b = synth_case(oracle, sr, 1.0, 25.0, [12.5], seed=31, stream=2)
+    cfg = gpu.Config(chunk_size_s=10.0, overlap_length_s=1.0, distance_s=5.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    other = gpu.HipConvolve(needle[::-1].copy())
+    exp_a = oracle.calc_chunks(sr, hay_a, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+    exp_b = oracle.calc_chunks(sr, hay_b, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+    exp_win = oracle.correlate(hay_a[:20000], needle, oracle.MODE_VALID, oracle.SCALE_LIB)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                if i % 3 == 0:
+                    assert_same(algo.match(hay_a, p), exp_a)
+                elif i % 3 == 1:
+                    assert_same(algo.match(hay_b, p), exp_b)
+                else:
+                    got = algo.correlate_with_sample(hay_a[:20000], gpu.Mode.Valid, True)
+                    assert np.abs(got - exp_win).max() < TOL
+                    assert other.match(hay_b, p) == []
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_error_codes(gpu):
+    import ctypes as C
+    L = gpu.lib()
+    algo = gpu.HipConvolve(np.ones(8, np.float32))
+    n = C.c_size_t(0)
+    out = (C.c_float * 4)()
+    x = np.ones(100, np.float32)
+    # capacity too small: required length is reported
+    rc = L.am_correlate(algo._h, x.ctypes.data, x.size, 2, 0, out, 4, C.byref(n))
+    assert rc == gpu.AM_ERR_CAPACITY and n.value == 93
+    assert L.am_correlate(algo._h, x.ctypes.data, x.size, 7, 0, out, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
+    assert L.am_correlate(None, x.ctypes.data, x.size, 2, 0, out, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
+    p = gpu.Config().params(8000, gpu.Scale.MY)
+    buf = (gpu.AmPeak * 4)()
+    assert L.am_match(algo._h, x.ctypes.data, x.size, C.byref(p), buf, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
+    p = gpu.Config().params(8000, gpu.Scale.LIB)
+    p.chunk = 0
+    assert L.am_match(algo._h, x.ctypes.data, x.size, C.byref(p), buf, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
+    h = C.c_void_p()
+    assert L.am_needle_create(99, x.ctypes.data, 8, C.byref(h)) == gpu.AM_ERR_NO_DEVICE
+    assert L.am_needle_create(0, x.ctypes.data, 0, C.byref(h)) == gpu.AM_ERR_INVALID_ARG
+    # peak-capacity overflow on am_match: count is reported
+    sr = 8000
+    y = np.zeros(4 * sr, np.float32)
+    spike = gpu.HipConvolve(np.array([1.0], np.float32))
+    y[[1000, 9000, 17000, 25000]] = 1.0
+    cfg = gpu.Config(chunk_size_s=1.0, overlap_length_s=0.0, distance_s=0.0, prominence=0.5)
+    pp = cfg.params(sr, gpu.Scale.LIB)
+    small = (gpu.AmPeak * 2)()
+    rc = L.am_match(spike._h, y.ctypes.data, y.size, C.byref(pp), small, 2, C.byref(n))
+    assert rc == gpu.AM_ERR_CAPACITY and n.value == 4
