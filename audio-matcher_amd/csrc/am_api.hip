@@ -49,6 +49,8 @@ static void* g_progress_user = nullptr;
 // tuning knobs
 static long long g_opt_log_n = 0;          // 0 = auto
 static long long g_opt_pairs_per_group = 64;
+static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
+static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
 
@@ -313,15 +315,20 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
             scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         }
     }
+    // half-precision storage of the work matrix: K2 normalises by the needle
+    // energy (times a fixed gain) so that stored values sit mid-range in f16
+    const bool half = g_opt_half && plan_is_r16(pl->dev) && g_k2_variant == 0;
+    const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
+    const float k3scale = half ? factor / hscale : factor;
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
     for (long long first = 0; first < npairs; first += ppg) {
         const int np = (int)std::min(ppg, npairs - first);
         job.first_pair = (int)first;
-        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev)); }
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev)); }
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, factor, scan)); }
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
     }
     return AM_OK;
 }
@@ -588,7 +595,8 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     job.src = d_hay; job.src_len = (long long)len; job.lead = 0; job.src_kind = src_kind;
     job.dst = (float*)c->scores.p; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
     job.first_pair = 0;
-    { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)npairs, (float2*)c->work.p, pl->dev)); }
+    const bool half = g_opt_half && plan_is_r16(pl->dev) && g_k2_variant == 0;
+    { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)npairs, (float2*)c->work.p, pl->dev, half)); }
     for (size_t k = 0; k < nn; ++k) {
         am_needle* h = needles[k];
         ScanRequest scan{};
@@ -603,9 +611,11 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
             cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
             scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         }
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p)); }
+        const float factor = scale_factor(h, p->scale, 1);
+        const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, half, hscale)); }
         { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, (const float2*)c->work2.p, pl->dev,
-                                                  scale_factor(h, p->scale, 1), cfg)); }
+                                                  half ? factor / hscale : factor, cfg, half)); }
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
                               (long long)p->min_distance, &scan, (int)(k * nsegs)))) return rc;
     }
@@ -1062,6 +1072,7 @@ int am_set_option(const char* key, long long value) {
         if (value != 0 && (value < kLogNMin || value > kLogNMax)) return fail(AM_ERR_INVALID_ARG, "log_n out of range");
         g_opt_log_n = value; return AM_OK;
     }
+    if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "k2_variant")) {
         if (value < 0 || value > 1) return fail(AM_ERR_INVALID_ARG, "k2_variant must be 0 or 1");
         g_k2_variant = (int)value; return AM_OK;
@@ -1077,6 +1088,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "log_n")) { *value = g_opt_log_n; return AM_OK; }
     if (!strcmp(key, "pairs_per_group")) { *value = g_opt_pairs_per_group; return AM_OK; }
     if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
+    if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }
 

@@ -36,6 +36,7 @@
 #include "am_kernels.h"
 
 #include <float.h>
+#include <hip/hip_fp16.h>
 
 namespace am {
 
@@ -146,6 +147,29 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
 }
 
+// Half-precision STORAGE of the work matrix (option "half_pipeline", BASELINE
+// config 5): every point travels through HBM as one __half2 (4 bytes instead of
+// 8); butterflies, twiddles and the spectrum multiply stay in f32 registers.
+__device__ __forceinline__ unsigned pack_h2(float2 v) {
+    const __half2 h = __float22half2_rn(v);
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float2 unpack_h2(unsigned u) {
+    return __half22float2(__builtin_bit_cast(__half2, u));
+}
+__device__ __forceinline__ uint2 buf_load_u2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    // element-wise through scalars: __builtin_bit_cast on a vector ELEMENT reads the
+    // vector's first lane for every element (observed with ROCm 7.2's clang)
+    const float lo = v.x, hi = v.y;
+    return make_uint2(__float_as_uint(lo), __float_as_uint(hi));
+}
+__device__ __forceinline__ void buf_store_u2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, uint2 v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 o; o.x = v.x; o.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
+}
+
 // ===========================================================================
 // Production kernels: N1 = 256 (16 x 16), N2 = 8192 (16 x 16 x 32), 256 threads
 // ===========================================================================
@@ -181,7 +205,7 @@ __device__ __forceinline__ float2 load2_padded(const void* __restrict__ src, lon
 // K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
 // FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
 // holds frequency k1 in natural order.
-template <int KIND>
+template <int KIND, bool HALF>
 __global__ void __launch_bounds__(256, 3)
 k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
@@ -259,6 +283,15 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
         twiddle_brev<16, false>(x0, step0);
         twiddle_brev<16, false>(x1, step1);
     }
+    if (HALF) {
+        uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bp = 0; bp < 16; ++bp) {
+            const size_t k1 = (size_t)(hi + 16 * bp);
+            out2[k1 * (kN2 / 2)] = make_uint2(pack_h2(x0[brev<16>(bp)]), pack_h2(x1[brev<16>(bp)]));
+        }
+        return;
+    }
     float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
@@ -272,10 +305,10 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
 // inverse FFT.  SPECTRUM = true stores conj(FFT)/N of the needle instead
 // (fft_b, the conj of pairwise_mult_in_place and the 1/len of
 // audio_matcher.rs:430-442 folded into one table).
-template <bool SPECTRUM>
+template <bool SPECTRUM, bool HALF>
 __global__ void __launch_bounds__(256, 2)
 k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl,
-            unsigned npairs) {
+            unsigned npairs, float hscale) {
     extern __shared__ float4 lds4[];
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
@@ -285,15 +318,23 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
     const unsigned row = (seq / npairs) * 8u + xcd, slot = seq % npairs;
     const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
-    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
+    // one point is 8 bytes (float2) or, with half storage, 4 bytes (__half2)
+    const __amdgpu_buffer_rsrc_t rrow = HALF ? make_rsrc(reinterpret_cast<unsigned*>(work) + row_off, kN2 * 4)
+                                             : make_rsrc(work + row_off, kN2 * 8);
     const size_t hoff4 = (size_t)row * (kN2 / 2);
     const unsigned voff = (unsigned)t * 16u;
     float2 x0[16], x1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
-        const float4 v = buf_load4(rrow, voff, a * 4096);
-        x0[a] = make_float2(v.x, v.y);
-        x1[a] = make_float2(v.z, v.w);
+        if (HALF) {
+            const uint2 v = buf_load_u2(rrow, voff / 2, a * 2048);
+            x0[a] = unpack_h2(v.x);
+            x1[a] = unpack_h2(v.y);
+        } else {
+            const float4 v = buf_load4(rrow, voff, a * 4096);
+            x0[a] = make_float2(v.x, v.y);
+            x1[a] = make_float2(v.z, v.w);
+        }
     }
     // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1 ----
     dif<16, false>(x0);
@@ -353,8 +394,9 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     float2 q[32];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float2 m0 = cmul(z[2 * i], make_float2(h[i].x, h[i].y));
-        const float2 m1 = cmul(z[2 * i + 1], make_float2(h[i].z, h[i].w));
+        // hscale != 1 only with half storage: keeps the stored values well inside f16's range
+        const float2 m0 = cmul(z[2 * i], make_float2(h[i].x * hscale, h[i].y * hscale));
+        const float2 m1 = cmul(z[2 * i + 1], make_float2(h[i].z * hscale, h[i].w * hscale));
         // z[r] holds frequency brev(r): hand the inverse its input in natural order
         q[brev<32>(2 * i)] = m0;
         q[brev<32>(2 * i + 1)] = m1;
@@ -396,6 +438,13 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     dif<16, true>(x1);
     // in place, or into a second work matrix (hc_out doubles as that destination
     // when several needles share one forward pass, am_match_multi_device)
+    if (HALF) {
+        const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(reinterpret_cast<unsigned*>(hc_out) + row_off, kN2 * 4) : rrow;
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            buf_store_u2(rdst, voff / 2, a * 2048, make_uint2(pack_h2(x0[brev<16>(a)]), pack_h2(x1[brev<16>(a)])));
+        return;
+    }
     const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(hc_out + row_off, kN2 * 8) : rrow;
 #pragma unroll
     for (int a = 0; a < 16; ++a)
@@ -596,6 +645,7 @@ __device__ __forceinline__ float group16_max(float v) {
 // K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
+template <bool HALF>
 __global__ void __launch_bounds__(256, 3)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -612,12 +662,22 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     const long long N = 1ll << pl.logN;
     const long long col = n2_0 + 2 * cp;
     float2 x0[16], x1[16];
-    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+    if (HALF) {
+        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
 #pragma unroll
-    for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
-        const float4 v = in4[(size_t)(hi + 16 * bp) * (kN2 / 2)];
-        x0[bp] = make_float2(v.x, v.y);
-        x1[bp] = make_float2(v.z, v.w);
+        for (int bp = 0; bp < 16; ++bp) {
+            const uint2 v = in2[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+            x0[bp] = unpack_h2(v.x);
+            x1[bp] = unpack_h2(v.y);
+        }
+    } else {
+        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
+            const float4 v = in4[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+            x0[bp] = make_float2(v.x, v.y);
+            x1[bp] = make_float2(v.z, v.w);
+        }
     }
     const unsigned maskN = (unsigned)(N - 1);
     {
@@ -945,23 +1005,32 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k3_cols_inv_gen<kColsLog>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<false>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<true>, kMaxLds)
-    AM_SET_LDS(k1_cols_fwd_r16<0>, kR16LdsK1)
-    AM_SET_LDS(k1_cols_fwd_r16<1>, kR16LdsK1)
-    AM_SET_LDS(k3_cols_inv_r16, kR16LdsK3)
-    AM_SET_LDS(k2_rows_r16<false>, kR16Lds)
-    AM_SET_LDS(k2_rows_r16<true>, kR16Lds)
+    AM_SET_LDS((k1_cols_fwd_r16<0, false>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<1, false>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<0, true>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<1, true>), kR16LdsK1)
+    AM_SET_LDS(k3_cols_inv_r16<false>, kR16LdsK3)
+    AM_SET_LDS(k3_cols_inv_r16<true>, kR16LdsK3)
+    AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
+    AM_SET_LDS((k2_rows_r16<false, true>), kR16Lds)
+    AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
     AM_SET_LDS(k2_rows_p512<false>, kR16Lds)
     AM_SET_LDS(k2_rows_p512<true>, kR16Lds)
 #undef AM_SET_LDS
     return hipSuccess;
 }
 
-hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl) {
+hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     const bool pcm = job.src_kind == 1;
     if (plan_is_r16(pl)) {
-        if (pcm) hipLaunchKernelGGL(k1_cols_fwd_r16<1>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
-        else hipLaunchKernelGGL(k1_cols_fwd_r16<0>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        if (half) {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        } else {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, false>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, false>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        }
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
         if (pcm) hipLaunchKernelGGL((k1_cols_fwd_gen<kColsLog, 1>), grid, dim3(kFftThreads), lds, st, job, work, pl);
@@ -970,14 +1039,17 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
     return hipGetLastError();
 }
 
-hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst) {
+hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst,
+                     bool half, float hscale) {
     const dim3 grid(1u << pl.logN1, npairs);
     if (plan_is_r16(pl) && g_k2_variant == 1) {
         hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << pl.logN1), dim3(512), kR16Lds, st, work, hc,
                            dst, pl, (unsigned)npairs);
     } else if (plan_is_r16(pl)) {
-        hipLaunchKernelGGL(k2_rows_r16<false>, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
-                           dst, pl, (unsigned)npairs);
+        if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+                                     dst, pl, (unsigned)npairs, hscale);
+        else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+                                dst, pl, (unsigned)npairs, 1.0f);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
         hipLaunchKernelGGL(k2_rows_gen<false>, grid, dim3(kFftThreads), lds, st, work, hc, dst, pl);
@@ -991,8 +1063,8 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
         hipLaunchKernelGGL(k2_rows_p512<true>, dim3(1u << pl.logN1), dim3(512), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u);
     } else if (plan_is_r16(pl)) {
-        hipLaunchKernelGGL(k2_rows_r16<true>, dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
-                           hc_out, pl, 1u);
+        hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
+                           hc_out, pl, 1u, 1.0f);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
         hipLaunchKernelGGL(k2_rows_gen<true>, grid, dim3(kFftThreads), lds, st, work, (const float2*)nullptr, hc_out, pl);
@@ -1002,11 +1074,13 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
 
 // scan.stats32 != nullptr only for the r16 plan with a 1024-aligned hop
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan) {
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl)) {
-        hipLaunchKernelGGL(k3_cols_inv_r16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
-                           pl, out_scale, scan);
+        if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+                                     pl, out_scale, scan);
+        else hipLaunchKernelGGL(k3_cols_inv_r16<false>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+                                pl, out_scale, scan);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
         hipLaunchKernelGGL(k3_cols_inv_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl, out_scale);

@@ -45,9 +45,11 @@ struct Segment {
     long long a, b;       // [a, b) in the score array
 };
 
-hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl);
+// half = store the work matrix as __half2 per point (r16 plan, K2 variant 0 only)
+hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half = false);
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
-hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr);
+hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
+                     bool half = false, float hscale = 1.0f);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
 // The score scan fused into K3 (r16 plan only).  stats32 == nullptr disables it
 // (plain correlation: every score is written).
@@ -59,7 +61,7 @@ struct ScanCfg {
     double inv_c;             // 1.0 / seg_c
 };
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan);
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half = false);
 bool plan_is_r16(const PlanDev& pl);
 extern int g_k2_variant;
 hipError_t fft_kernels_init();

@@ -191,7 +191,11 @@ int am_profile_enable(int device, int on);
 int am_profile_reset(int device);
 int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t* launches);
 
-/* tuning knobs: "log_n" (0 = auto), "pairs_per_group" */
+/* options:
+ *   "log_n" (0 = auto), "pairs_per_group", "k2_variant" (0/1): tuning knobs
+ *   "half_pipeline" (0/1): store the transform's work matrix in half precision
+ *       (BASELINE config 5).  Butterflies stay f32; scores then carry an absolute
+ *       error of about 1e-5 of the chunk's score range, hit offsets are unaffected. */
 int am_set_option(const char* key, long long value);
 int am_get_option(const char* key, long long* value);
 

@@ -334,3 +334,41 @@ def test_error_codes(gpu):
     small = (gpu.AmPeak * 2)()
     rc = L.am_match(spike._h, y.ctypes.data, y.size, C.byref(pp), small, 2, C.byref(n))
     assert rc == gpu.AM_ERR_CAPACITY and n.value == 4
+
+
+def test_half_pipeline_config5(gpu, oracle):
+    """BASELINE config 5: 48 kHz interleaved i16 stereo through the half-precision
+    pipeline (work matrix stored as f16).  SURVEY 7: offset parity is the promise;
+    scores are additionally checked to 1e-3."""
+    sr = 48000
+    rng = np.random.default_rng(77)
+    s, h = 10 * sr, 250 * sr
+    needle_lr = rng.integers(-9000, 9000, size=2 * s).astype(np.int16)
+    hay_lr = rng.integers(-9000, 9000, size=2 * h).astype(np.int32)
+    for t in (17.0, 71.3, 140.0, 222.2):
+        off = int(t * sr)
+        hay_lr[2 * off:2 * (off + s)] += needle_lr
+    hay_lr = np.clip(hay_lr, -32768, 32767).astype(np.int16)
+    needle = oracle.pcm_s16_stereo_to_mono(needle_lr)
+    hay = oracle.pcm_s16_stereo_to_mono(hay_lr)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=30.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+    assert len(exp) == 4
+    gpu.set_option("half_pipeline", 1)
+    try:
+        algo = gpu.HipConvolve.from_pcm16(needle_lr)
+        for _ in range(2):
+            got = algo.match_pcm16(hay_lr, p)
+            assert [g.start for g in got] == [e[0] for e in exp]          # identical integer offsets
+            for g, e in zip(got, exp):
+                assert abs(g.height - e[2]) < 1e-3 and abs(g.prominence - e[3]) < 1e-3
+        # level 1 through the same pipeline: bounded error on the whole score vector
+        win = hay[: 3 * 1024 * 1024]
+        sc = algo.correlate_with_sample(win, gpu.Mode.Valid, True)
+        ref = oracle.correlate(win, needle, oracle.MODE_VALID, oracle.SCALE_LIB)
+        assert np.abs(sc - ref).max() < 1e-3
+        err = float(np.abs(sc - ref).max())
+    finally:
+        gpu.set_option("half_pipeline", 0)
+    print("half pipeline max score error", err)
