@@ -122,6 +122,19 @@ __device__ __forceinline__ void twiddle_apply(float2* x, float2 w) {
         x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], v);
     }
 }
+// x[idx(e)] *= base * step^e (or the conjugates), e = 0..R-1, as one running
+// product c[e] = c[e-1] * step: R-1 products instead of a separate base pass.
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_chain(float2* x, float2 base, float2 step) {
+    if (CONJ) { base.y = -base.y; step.y = -step.y; }
+    float2 c = base;
+    x[0] = cmul(x[0], c);
+#pragma unroll
+    for (int e = 1; e < R; ++e) {
+        c = cmul(c, step);
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], c);
+    }
+}
 template <int R, bool CONJ>
 __device__ __forceinline__ void twiddle_brev(float2* x, float2 w) { twiddle_apply<R, CONJ, true>(x, w); }
 template <int R, bool CONJ>
@@ -273,15 +286,8 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
         const float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
         const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
         const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
-        x0[0] = cmul(x0[0], base0);
-        x1[0] = cmul(x1[0], base1);
-#pragma unroll
-        for (int e = 1; e < 16; ++e) {
-            x0[brev<16>(e)] = cmul(x0[brev<16>(e)], base0);
-            x1[brev<16>(e)] = cmul(x1[brev<16>(e)], base1);
-        }
-        twiddle_brev<16, false>(x0, step0);
-        twiddle_brev<16, false>(x1, step1);
+        twiddle_chain<16, false, true>(x0, base0, step0);
+        twiddle_chain<16, false, true>(x1, base1, step1);
     }
     if (HALF) {
         uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
@@ -686,13 +692,8 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
         const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
         const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            x0[e] = cmulc(x0[e], base0);
-            x1[e] = cmulc(x1[e], base1);
-        }
-        twiddle_nat<16, true>(x0, step0);
-        twiddle_nat<16, true>(x1, step1);
+        twiddle_chain<16, true, false>(x0, base0, step0);
+        twiddle_chain<16, true, false>(x1, base1, step1);
     }
     dif<16, true>(x0);   // b at x[brev(b)]
     dif<16, true>(x1);
@@ -734,16 +735,30 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         // ---- fused score scan: (min,max) per 32 consecutive scores ------------
         float mnA[16], mxA[16], mnB[16], mxB[16];
         float tmaxA = -FLT_MAX, tmaxB = -FLT_MAX;
+        const int limAi = (int)limA, limBi = (int)(limB > 0 ? limB : 0);   // <= hop < 2^31
+        if (((limAi | limBi) & 31) == 0) {
+            // every 32-score run is wholly valid or wholly invalid (always, except in
+            // the block that holds the end of the score array)
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * 16 + hi) * kN2 + col;
-            const bool a0v = n < limA, a1v = n + 1 < limA, b0v = n < limB, b1v = n + 1 < limB;
-            mnA[a] = fminf(a0v ? sa0[a] : FLT_MAX, a1v ? sa1[a] : FLT_MAX);
-            mxA[a] = fmaxf(a0v ? sa0[a] : -FLT_MAX, a1v ? sa1[a] : -FLT_MAX);
-            mnB[a] = fminf(b0v ? sb0[a] : FLT_MAX, b1v ? sb1[a] : FLT_MAX);
-            mxB[a] = fmaxf(b0v ? sb0[a] : -FLT_MAX, b1v ? sb1[a] : -FLT_MAX);
-            tmaxA = fmaxf(tmaxA, mxA[a]);
-            tmaxB = fmaxf(tmaxB, mxB[a]);
+            for (int a = 0; a < 16; ++a) {
+                const int run = (a * 16 + hi) * kN2 + n2_0;
+                mnA[a] = fminf(sa0[a], sa1[a]); mxA[a] = fmaxf(sa0[a], sa1[a]);
+                mnB[a] = fminf(sb0[a], sb1[a]); mxB[a] = fmaxf(sb0[a], sb1[a]);
+                tmaxA = run < limAi ? fmaxf(tmaxA, mxA[a]) : tmaxA;
+                tmaxB = run < limBi ? fmaxf(tmaxB, mxB[a]) : tmaxB;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                const int n = (a * 16 + hi) * kN2 + (int)col;
+                const bool a0v = n < limAi, a1v = n + 1 < limAi, b0v = n < limBi, b1v = n + 1 < limBi;
+                mnA[a] = fminf(a0v ? sa0[a] : FLT_MAX, a1v ? sa1[a] : FLT_MAX);
+                mxA[a] = fmaxf(a0v ? sa0[a] : -FLT_MAX, a1v ? sa1[a] : -FLT_MAX);
+                mnB[a] = fminf(b0v ? sb0[a] : FLT_MAX, b1v ? sb1[a] : FLT_MAX);
+                mxB[a] = fmaxf(b0v ? sb0[a] : -FLT_MAX, b1v ? sb1[a] : -FLT_MAX);
+                tmaxA = fmaxf(tmaxA, mxA[a]);
+                tmaxB = fmaxf(tmaxB, mxB[a]);
+            }
         }
         // raw scores leave the chip only for tiles that can matter to the peak
         // pick: some score >= theta, or a run that straddles a chunk edge
