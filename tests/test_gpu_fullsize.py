@@ -1,0 +1,88 @@
+"""Full-size (BASELINE configs[1]: 10 s needle vs 1 h haystack, 44.1 kHz) checks through
+size-independent properties, since the oracle needs minutes at this size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SR = 44100
+S = 10 * SR
+H = 3600 * SR
+
+
+def plant_offsets(k):
+    return [600 * SR * m + 30 * SR + 17 * k + 1234 for m in range(6)]
+
+
+@pytest.fixture(scope="module")
+def full(gpu):
+    needle = gpu.synth_uniform_device(0, S, seed=1, stream=0)
+    algo = gpu.HipConvolve.from_device(0, needle.ptr, S)
+    hay = gpu.synth_uniform_device(0, H, seed=1, stream=1)
+    for t in plant_offsets(0):
+        gpu.axpy_device(0, hay, t, needle.ptr, S, 1.0)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=480.0, prominence=0.13)
+    return gpu, needle, algo, hay, cfg.params(SR, gpu.Scale.LIB)
+
+
+def test_planted_offsets_recovered_and_idempotent(full):
+    gpu, needle, algo, hay, p = full
+    first = algo.match_device(hay.ptr, H, p)       # first call: every score written
+    second = algo.match_device(hay.ptr, H, p)      # later calls: sparse scores
+    third = algo.match_device(hay.ptr, H, p)
+    assert [q.start for q in first] == plant_offsets(0)
+    key = lambda r: [(q.start, q.end, q.height, q.prominence) for q in r]
+    assert key(first) == key(second) == key(third)  # bitwise idempotent across the two score paths
+    for q in first:
+        assert abs(q.height - 1.0) < 0.02 and q.prominence > 0.9
+
+
+def test_shift_equivariance(full):
+    """Matching a haystack that starts 12 345 samples later moves every offset by -12 345."""
+    gpu, needle, algo, hay, p = full
+    k = 12345
+    shifted = algo.match_device(hay.ptr + 4 * k, H - k, p)
+    assert [q.start for q in shifted] == [t - k for t in plant_offsets(0)]
+
+
+def test_score_checksum_full_vector(full, oracle):
+    """Sum of all H-S+1 scores against the closed form sum_n needle[n]*(P[n+J]-P[n]) / E,
+    P = prefix sums of the haystack (f64 on the host)."""
+    gpu, needle, algo, hay, p = full
+    J = H - S + 1
+    out = gpu.DeviceBuffer(0, 4 * J)
+    n = __import__("ctypes").c_size_t(0)
+    gpu._check(gpu.lib().am_correlate_device(algo._h, hay.ptr, H, int(gpu.Mode.Valid), int(gpu.Scale.LIB),
+                                            out.ptr, J, __import__("ctypes").byref(n)))
+    assert n.value == J
+    scores = out.to_numpy(np.float32, J)
+    h_host = hay.to_numpy(np.float32, H)
+    n_host = needle.to_numpy(np.float32, S)
+    P = np.concatenate(([0.0], np.cumsum(h_host, dtype=np.float64)))
+    e = float(np.sum(n_host.astype(np.float64) ** 2))
+    idx = np.arange(S)
+    expect = float(np.sum(n_host.astype(np.float64) * (P[idx + J] - P[idx]))) / e
+    got = float(np.sum(scores, dtype=np.float64))
+    # tolerance: J * per-score error budget (1e-6) is far above f32 accumulation noise here
+    assert abs(got - expect) < 1e-6 * J
+    # weighted checksum (alternating signs) catches permutations that a plain sum cannot
+    w = np.where(np.arange(J) & 1, -1.0, 1.0)
+    alt = np.concatenate(([0.0], np.cumsum(h_host.astype(np.float64) * np.where(np.arange(H) & 1, -1.0, 1.0))))
+    expect_alt = float(np.sum(n_host.astype(np.float64) * np.where(idx & 1, -1.0, 1.0) * (alt[idx + J] - alt[idx]))) / e
+    got_alt = float(np.sum(scores.astype(np.float64) * w))
+    assert abs(got_alt - expect_alt) < 1e-6 * J
+    # spot values against the direct definition
+    for j in (0, 1, 777_777, plant_offsets(0)[2], J - 1):
+        direct = float(np.dot(h_host[j:j + S].astype(np.float64), n_host.astype(np.float64))) / e
+        assert abs(float(scores[j]) - direct) < 1e-4
+
+
+def test_batch_equals_singles_full_size(full):
+    gpu, needle, algo, hay, p = full
+    hay2 = gpu.synth_uniform_device(0, H, seed=1, stream=2)
+    for t in plant_offsets(1):
+        gpu.axpy_device(0, hay2, t, needle.ptr, S, 1.0)
+    res = algo.match_batch_device([hay.ptr, hay2.ptr, hay.ptr], [H, H, H], p)
+    assert [q.start for q in res[0]] == plant_offsets(0)
+    assert [q.start for q in res[1]] == plant_offsets(1)
+    assert [(q.start, q.height) for q in res[2]] == [(q.start, q.height) for q in res[0]]
