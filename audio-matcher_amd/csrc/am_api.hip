@@ -49,6 +49,7 @@ static void* g_progress_user = nullptr;
 // tuning knobs
 static long long g_opt_log_n = 0;          // 0 = auto
 static long long g_opt_pairs_per_group = 64;
+static long long g_opt_lanes = 1;           // 2 = overlap the kernels of alternate pair groups on two streams
 static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
@@ -98,6 +99,8 @@ enum { KN_K1 = 0, KN_K2, KN_K3, KN_STATS, KN_PEAKS, KN_OTHER, KN_COUNT };
 struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // second lane of the two-lane block pipeline
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
     DevBuf work, work2, scores, stats, stats32, wflags, segs, hdr, peaks, counts, io_in, io_out, sum;
@@ -133,6 +136,10 @@ static int get_ctx(int device, Ctx** out) {
     c->device = device;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
+    (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
     g_ctx[device] = c;
     *out = c;
     return AM_OK;
@@ -146,17 +153,18 @@ static hipEvent_t prof_event(Ctx* c) {
     return e;
 }
 struct ProfScope {
-    Ctx* c; int name; hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(Ctx* c_, int name_) : c(c_), name(name_) {
-        if (c->prof) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, c->stream); }
+    Ctx* c; int name; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(Ctx* c_, int name_, hipStream_t st_ = nullptr) : c(c_), name(name_), st(st_ ? st_ : c_->stream) {
+        if (c->prof) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
-        if (c->prof) { (void)hipEventRecord(e1, c->stream); c->pending.push_back({name, e0, e1}); }
+        if (c->prof) { (void)hipEventRecord(e1, st); c->pending.push_back({name, e0, e1}); }
     }
 };
 static void prof_harvest(Ctx* c) {
     if (c->pending.empty()) return;
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto& r : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { c->prof_ms[r.name] += ms; c->prof_n[r.name] += 1; }
@@ -323,13 +331,43 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
-    for (long long first = 0; first < npairs; first += ppg) {
-        const int np = (int)std::min(ppg, npairs - first);
-        job.first_pair = (int)first;
-        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
+    const bool two_lanes = g_opt_lanes == 2 && c->stream2 && c->ev_a && c->ev_b && c->ev_c && npairs >= 8 && ppg >= npairs;
+    if (!two_lanes) {
+        for (long long first = 0; first < npairs; first += ppg) {
+            const int np = (int)std::min(ppg, npairs - first);
+            job.first_pair = (int)first;
+            { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
+            { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
+            { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
+        }
+        return AM_OK;
     }
+    // Two-lane pipeline: the pairs are cut into four groups that alternate between
+    // two streams, the second lane one kernel behind the first, so that a
+    // bandwidth-heavy kernel of one group runs beside a latency/VALU-heavy kernel
+    // of the other.  Groups write disjoint parts of the score arrays; each lane has
+    // its own half of the work matrix (the whole matrix was sized for all pairs).
+    const long long gsz = (npairs + 3) / 4;
+    hipStream_t lane[2] = {c->stream, c->stream2};
+    // each lane owns gsz pair slots of the work matrix; groups g and g+2 reuse them in stream order
+    float2* wk[2] = {(float2*)c->work.p, (float2*)c->work.p + (size_t)gsz * (size_t)N};
+    AM_HIP(hipEventRecord(c->ev_a, c->stream));            // everything queued before this call
+    AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_a, 0));
+    int g = 0;
+    for (long long first = 0; first < npairs; first += gsz, ++g) {
+        const int ln = g & 1;
+        const int np = (int)std::min(gsz, npairs - first);
+        job.first_pair = (int)first;
+        { ProfScope ps(c, KN_K1, lane[ln]); AM_HIP(launch_k1(lane[ln], job, np, wk[ln], pl->dev, half)); }
+        if (g == 0) {                                       // stagger: lane 1 starts after lane 0's first K1
+            AM_HIP(hipEventRecord(c->ev_b, lane[0]));
+            AM_HIP(hipStreamWaitEvent(lane[1], c->ev_b, 0));
+        }
+        { ProfScope ps(c, KN_K2, lane[ln]); AM_HIP(launch_k2(lane[ln], np, wk[ln], hc, pl->dev, nullptr, half, hscale)); }
+        { ProfScope ps(c, KN_K3, lane[ln]); AM_HIP(launch_k3(lane[ln], job, np, wk[ln], pl->dev, k3scale, scan, half)); }
+    }
+    AM_HIP(hipEventRecord(c->ev_c, c->stream2));           // join: the main stream continues after both lanes
+    AM_HIP(hipStreamWaitEvent(c->stream, c->ev_c, 0));
     return AM_OK;
 }
 
@@ -1073,6 +1111,10 @@ int am_set_option(const char* key, long long value) {
         g_opt_log_n = value; return AM_OK;
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "lanes")) {
+        if (value != 1 && value != 2) return fail(AM_ERR_INVALID_ARG, "lanes must be 1 or 2");
+        g_opt_lanes = value; return AM_OK;
+    }
     if (!strcmp(key, "k2_variant")) {
         if (value < 0 || value > 1) return fail(AM_ERR_INVALID_ARG, "k2_variant must be 0 or 1");
         g_k2_variant = (int)value; return AM_OK;
@@ -1089,6 +1131,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "pairs_per_group")) { *value = g_opt_pairs_per_group; return AM_OK; }
     if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
     if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
+    if (!strcmp(key, "lanes")) { *value = g_opt_lanes; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }
 
