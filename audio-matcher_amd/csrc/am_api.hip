@@ -49,6 +49,7 @@ static void* g_progress_user = nullptr;
 // tuning knobs
 static long long g_opt_log_n = 0;          // 0 = auto
 static long long g_opt_pairs_per_group = 64;
+static long long g_opt_profile_mask = -1;    // bit i = bracket kernel class i with events while profiling is on
 static long long g_opt_lanes = 1;           // 2 = overlap the kernels of alternate pair groups on two streams
 static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
@@ -154,11 +155,13 @@ static hipEvent_t prof_event(Ctx* c) {
 }
 struct ProfScope {
     Ctx* c; int name; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on;
     ProfScope(Ctx* c_, int name_, hipStream_t st_ = nullptr) : c(c_), name(name_), st(st_ ? st_ : c_->stream) {
-        if (c->prof) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, st); }
+        on = c->prof && ((g_opt_profile_mask >> name) & 1);
+        if (on) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
-        if (c->prof) { (void)hipEventRecord(e1, st); c->pending.push_back({name, e0, e1}); }
+        if (on) { (void)hipEventRecord(e1, st); c->pending.push_back({name, e0, e1}); }
     }
 };
 static void prof_harvest(Ctx* c) {
@@ -1111,6 +1114,7 @@ int am_set_option(const char* key, long long value) {
         g_opt_log_n = value; return AM_OK;
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "profile_mask")) { g_opt_profile_mask = value; return AM_OK; }
     if (!strcmp(key, "lanes")) {
         if (value != 1 && value != 2) return fail(AM_ERR_INVALID_ARG, "lanes must be 1 or 2");
         g_opt_lanes = value; return AM_OK;
@@ -1132,6 +1136,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
     if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
     if (!strcmp(key, "lanes")) { *value = g_opt_lanes; return AM_OK; }
+    if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }
 
