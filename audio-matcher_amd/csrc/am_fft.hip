@@ -307,6 +307,14 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
+// Ordering point for an LDS exchange whose writers and readers are lanes of the
+// same wavefront: LDS serves one wave's instructions in issue order, so only the
+// compiler has to be kept from moving the accesses across it.
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // K2: one 8192-point row: forward FFT (16 x 16 x 32), multiply by conj(H)/N,
 // inverse FFT.  SPECTRUM = true stores conj(FFT)/N of the needle instead
 // (fft_b, the conj of pairwise_mult_in_place and the 1/len of
@@ -329,6 +337,10 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
                                              : make_rsrc(work + row_off, kN2 * 8);
     const size_t hoff4 = (size_t)row * (kN2 / 2);
     const unsigned voff = (unsigned)t * 16u;
+    // twiddle seeds of both pass boundaries, fetched beside the row so that their
+    // (L2) latency is not exposed in the middle of the transform
+    const float2 wj0 = pl.tw2[2 * t], wj1 = pl.tw2[2 * t + 1];
+    const float2 wc0 = pl.tw2[32 * cp], wc1 = pl.tw2[32 * cp + 16];
     float2 x0[16], x1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
@@ -345,7 +357,6 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1 ----
     dif<16, false>(x0);
     dif<16, false>(x1);
-    const float2 wj0 = pl.tw2[2 * t], wj1 = pl.tw2[2 * t + 1];
     twiddle_brev<16, false>(x0, wj0);
     twiddle_brev<16, false>(x1, wj1);
 #pragma unroll
@@ -362,15 +373,14 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
-    const float2 wc0 = pl.tw2[32 * cp], wc1 = pl.tw2[32 * cp + 16];
     twiddle_brev<16, false>(x0, wc0);
     twiddle_brev<16, false>(x1, wc1);
-    __syncthreads();
+    wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp)   // L2 row u = a'*16 + b', slot cp ^ b'
         lds4[(hi * 16 + bp) * 16 + (cp ^ bp)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
                                                             x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
-    __syncthreads();
+    wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
     // ---- pass 3 over c (32 contiguous): thread owns row u = t ----
     float2 z[32];
 #pragma unroll
@@ -413,7 +423,7 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     for (int i = 0; i < 16; ++i)   // own row again, no barrier needed before
         lds4[t * 16 + (i ^ cp)] = make_float4(q[brev<32>(2 * i)].x, q[brev<32>(2 * i)].y,
                                               q[brev<32>(2 * i + 1)].x, q[brev<32>(2 * i + 1)].y);
-    __syncthreads();
+    wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
     // ---- inverse pass 2 over b': conj twiddle first, then butterflies ----
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
@@ -425,7 +435,7 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     twiddle_nat<16, true>(x1, wc1);
     dif<16, true>(x0);
     dif<16, true>(x1);
-    __syncthreads();
+    wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
 #pragma unroll
     for (int b = 0; b < 16; ++b)
         lds4[hi * 256 + b * 16 + cp] = make_float4(x0[brev<16>(b)].x, x0[brev<16>(b)].y,
