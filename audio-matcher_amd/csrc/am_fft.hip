@@ -236,6 +236,15 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     float2 x0[16], x1[16];
     // pass 1 ownership: b = hi (n1 = a*16 + b), columns 2cp, 2cp+1
     const long long col = n2_0 + 2 * cp;
+    // every table lookup this workgroup needs, issued before the samples so that
+    // their latency overlaps the streaming loads: W_256^b for the pass boundary and
+    // W_N^(n2*a'), W_N^(16*n2) for the pipeline twiddle (k1 = a' + 16*b', a' = hi)
+    const unsigned maskN = (unsigned)(N - 1);
+    const float2 w256 = pl.tw1[hi];
+    const float2 base0 = tw_big(pl, ((unsigned)col * (unsigned)hi) & maskN);
+    const float2 base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)hi) & maskN);
+    const float2 step0 = tw_big(pl, ((unsigned)col * 16u) & maskN);
+    const float2 step1 = tw_big(pl, (((unsigned)col + 1u) * 16u) & maskN);
     if (fast) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
@@ -256,11 +265,8 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
-    {   // W_256^(b*a')
-        const float2 w = pl.tw1[hi];
-        twiddle_brev<16, false>(x0, w);
-        twiddle_brev<16, false>(x1, w);
-    }
+    twiddle_brev<16, false>(x0, w256);   // W_256^(b*a')
+    twiddle_brev<16, false>(x1, w256);
     // Exchange between the two passes, one column of the pair at a time so that a
     // workgroup needs 34 KB of LDS (row stride 17 keeps the 8-byte reads of rows
     // 16 apart on disjoint banks): pass 2 owns a' = hi, b = 0..15.
@@ -279,16 +285,8 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     dif<16, false>(x0);
     dif<16, false>(x1);
     // k1 = a' + 16*b';  W_N^(n2*k1) = W_N^(n2*a') * (W_N^(16*n2))^b'
-    const unsigned maskN = (unsigned)(N - 1);
-    {
-        const unsigned n2 = (unsigned)col;
-        const float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
-        const float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
-        const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
-        const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
-        twiddle_chain<16, false, true>(x0, base0, step0);
-        twiddle_chain<16, false, true>(x1, base1, step1);
-    }
+    twiddle_chain<16, false, true>(x0, base0, step0);
+    twiddle_chain<16, false, true>(x1, base1, step1);
     if (HALF) {
         uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
 #pragma unroll
@@ -665,7 +663,9 @@ template <bool HALF>
 __global__ void __launch_bounds__(256, 3)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
+    __shared__ int vote[2];
     const int t = threadIdx.x;
+    if (t < 2) vote[t] = 0;
     const int hi = t >> 4, cp = t & 15;
     // XCD-aware placement (speed only): the 16 adjacent column tiles that share
     // one 128-byte line of stats32 run on the same XCD, so the line is merged in
@@ -696,6 +696,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         }
     }
     const unsigned maskN = (unsigned)(N - 1);
+    const float2 w256 = pl.tw1[hi];
     {
         const unsigned n2 = (unsigned)col;
         float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
@@ -721,11 +722,8 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     __syncthreads();
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) x1[ap] = lds2[(ap * 16 + hi) * 16 + cp];
-    {
-        const float2 w = pl.tw1[hi];
-        twiddle_nat<16, true>(x0, w);
-        twiddle_nat<16, true>(x1, w);
-    }
+    twiddle_nat<16, true>(x0, w256);
+    twiddle_nat<16, true>(x1, w256);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
     const long long outA = blkA * job.hop, outB = blkB * job.hop;
@@ -775,8 +773,14 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         const long long rowrun = (long long)t * kN2 + n2_0;   // thread t checks row n1 = t
         const bool edgeA = rowrun < limA && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         const bool edgeB = rowrun < limB && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
-        wantA = __syncthreads_or((tmaxA >= scan.theta) || edgeA) != 0;
-        wantB = __syncthreads_or((tmaxB >= scan.theta) || edgeB) != 0;
+        // one block-wide vote for both blocks: per-wave ballots into two LDS words
+        // (zeroed before the exchange barriers above)
+        const bool pa = (tmaxA >= scan.theta) || edgeA, pb = (tmaxB >= scan.theta) || edgeB;
+        if (__ballot(pa) && (t & 63) == 0) vote[0] = 1;
+        if (__ballot(pb) && (t & 63) == 0) vote[1] = 1;
+        __syncthreads();
+        wantA = vote[0] != 0;
+        wantB = vote[1] != 0;
         if (t == 0 && scan.wflags != nullptr) {
             const unsigned tile = (unsigned)n2_0 >> kColsLog;
             scan.wflags[blkA * (kN2 >> kColsLog) + tile] = wantA ? 1 : 0;
