@@ -379,6 +379,16 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
         lds4[(hi * 16 + bp) * 16 + (cp ^ bp)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
                                                             x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
+    // the needle-spectrum row (L2-resident) is requested here, where only the 32
+    // points of pass 3 are live, so that its latency hides behind that pass
+    float4 h[16];
+    if (!SPECTRUM) {
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + hoff4, kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, voff, i * 4096);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- pass 3 over c (32 contiguous): thread owns row u = t ----
     float2 z[32];
 #pragma unroll
@@ -398,13 +408,6 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
         return;
     }
     // ---- pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438) ----
-    __builtin_amdgcn_sched_barrier(0);
-    float4 h[16];
-    {
-        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + hoff4, kN2 * 8);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, voff, i * 4096);
-    }
     float2 q[32];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
