@@ -1,0 +1,92 @@
+"""Randomised parity of calc_chunks (audio_matcher.rs:88-141) against the oracle over
+chunk / overlap / distance / prominence combinations the fixed tests do not reach:
+overlap shorter and longer than the needle, chunk lengths that are not multiples of
+anything, several hits per chunk, both transform plans (generic and the N = 2^21 one)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def build_case(oracle, rng, sr, s, h, n_plants, gain_lo=0.6):
+    needle = oracle.synth_uniform(int(rng.integers(1, 1 << 30)), 0, 0, s)
+    hay = oracle.synth_uniform(int(rng.integers(1, 1 << 30)), 1, 0, h)
+    offs = sorted(int(x) for x in rng.integers(0, max(1, h - s), size=n_plants))
+    for o in offs:
+        hay[o:o + s] += float(rng.uniform(gain_lo, 1.2)) * needle
+    return needle, hay
+
+
+def compare(gpu, oracle, needle, hay, sr, chunk, overlap, prom, dist_s, handle=None):
+    p = gpu.AmMatchParams(sr=sr, chunk=chunk, overlap=overlap, min_prominence=prom,
+                          min_distance=int(dist_s) * sr, overshadow_distance_s=dist_s, scale=1)
+    algo = handle or gpu.HipConvolve(needle)
+    exp = oracle.calc_chunks(sr, hay, needle, chunk, overlap, prom, p.min_distance, dist_s)
+    for _ in range(2):   # dense scores first, sparse scores on the second call
+        got = algo.match(hay, p)
+        assert [(g.start, g.end) for g in got] == [(e[0], e[1]) for e in exp]
+        for g, e in zip(got, exp):
+            assert abs(g.height - e[2]) < TOL and abs(g.prominence - e[3]) < TOL
+    return len(exp)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_small_plans(gpu, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    sr = 8000
+    s = int(rng.integers(2000, 12000))
+    h = int(rng.integers(12 * s, 40 * s))
+    needle, hay = build_case(oracle, rng, sr, s, h, int(rng.integers(0, 9)))
+    chunk = int(rng.integers(2 * s, 9 * s)) | 1                      # odd on purpose
+    overlap = int(rng.choice([0, s // 3, s - 1, s, s + 17, 2 * s]))
+    prom = float(rng.choice([0.2, 0.35, 0.5]))
+    dist_s = float(rng.choice([0.0, 1.0, 3.0, 30.0]))
+    compare(gpu, oracle, needle, hay, sr, chunk, overlap, prom, dist_s)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_production_plan(gpu, oracle, seed):
+    """Needles of 300k-500k samples select the N = 2^21 register kernels."""
+    rng = np.random.default_rng(2000 + seed)
+    sr = 44100
+    s = int(rng.integers(300_000, 500_000))
+    h = int(rng.integers(9_000_000, 14_000_000))
+    needle, hay = build_case(oracle, rng, sr, s, h, int(rng.integers(1, 6)))
+    chunk = int(rng.integers(2_000_000, 4_000_000)) | 1
+    overlap = int(rng.choice([s, s // 2, s + 999]))
+    dist_s = float(rng.choice([5.0, 60.0, 480.0]))
+    n = compare(gpu, oracle, needle, hay, sr, chunk, overlap, 0.13, dist_s)
+    assert n >= 0
+
+
+def test_find_peaks_random_vs_oracle(gpu, oracle):
+    """am_find_peaks on random walks / noise / quantised data with random thresholds and distances."""
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        n = int(rng.integers(3, 120_000))
+        kind = trial % 3
+        if kind == 0:
+            y = np.cumsum(rng.standard_normal(n)).astype(np.float32)
+        elif kind == 1:
+            y = rng.standard_normal(n).astype(np.float32)
+        else:
+            y = (np.round(rng.standard_normal(n) * 2) / 2).astype(np.float32)
+        prom = float(rng.choice([0.0, 0.5, 2.0, 8.0]))
+        dist = int(rng.choice([0, 1, 7, 500, 50_000]))
+        exp = oracle.find_peaks(y, prom, dist, cap=max(16, n))
+        if len(exp) > gpu.AM_MAX_PEAKS_PER_CHUNK:
+            # the documented limit applies to peaks that pass the prominence filter
+            pre = oracle.find_peaks(y, prom, 0, cap=max(16, n))
+            if len(pre) > gpu.AM_MAX_PEAKS_PER_CHUNK:
+                with pytest.raises(gpu.AudioMatchError):
+                    gpu.find_peaks(y, prom, dist)
+                continue
+        pre = oracle.find_peaks(y, prom, 0, cap=max(16, n))
+        if len(pre) > gpu.AM_MAX_PEAKS_PER_CHUNK:
+            with pytest.raises(gpu.AudioMatchError):
+                gpu.find_peaks(y, prom, dist)
+            continue
+        got = [(p.start, p.end, p.height, p.prominence) for p in gpu.find_peaks(y, prom, dist)]
+        assert got == exp, (trial, n, prom, dist)
