@@ -116,7 +116,6 @@ struct Ctx {
 
 static std::mutex g_ctx_mu;
 static std::map<int, Ctx*> g_ctx;
-static bool g_kernels_ready = false;
 
 static int get_ctx(int device, Ctx** out) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -129,10 +128,7 @@ static int get_ctx(int device, Ctx** out) {
     AM_HIP(hipSetDevice(device));
     (void)hipSetDeviceFlags(hipDeviceScheduleSpin);   // may fail if the primary context is already active: harmless
     (void)hipGetLastError();
-    if (!g_kernels_ready) {
-        AM_HIP(fft_kernels_init());
-        g_kernels_ready = true;
-    }
+    AM_HIP(fft_kernels_init());   // function attributes are per device
     Ctx* c = new Ctx();
     c->device = device;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -1064,6 +1060,28 @@ int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     AM_HIP(launch_axpy(c->stream, d_dst, d_src, (long long)n, gain));
     AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (auto& kv : g_ctx) {
+        Ctx* c = kv.second;
+        std::lock_guard<std::recursive_mutex> lk2(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs, &c->hdr,
+                          &c->peaks, &c->counts, &c->io_in, &c->io_out, &c->sum})
+            b->release();
+        if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
+        for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
+        c->plans.clear();
+        for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        c->pending.clear();
+        for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+        c->pool.clear();
+    }
     return AM_OK;
 }
 

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "am_abi_version": (C.c_int, []),
     "am_last_error_string": (C.c_char_p, []),
     "am_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "am_shutdown": (C.c_int, []),
     "am_needle_create": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "am_needle_create_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "am_needle_destroy": (None, [C.c_void_p]),

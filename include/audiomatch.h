@@ -82,6 +82,10 @@ typedef struct am_match_params {
 int am_abi_version(void);
 const char* am_last_error_string(void);
 int am_device_count(int* n);
+/* Releases every scratch buffer, transform plan and timing event the library
+ * holds on every device (needle handles stay valid and rebuild what they need
+ * on their next use).  Optional: everything is also released at process exit. */
+int am_shutdown(void);
 
 /* ---- needle handle ----------------------------------------------------- */
 /* LibConvolve::new(sample_data) audio_matcher.rs:289 / MyConvolve::new :396.

@@ -372,3 +372,16 @@ def test_half_pipeline_config5(gpu, oracle):
     finally:
         gpu.set_option("half_pipeline", 0)
     print("half pipeline max score error", err)
+
+
+def test_shutdown_releases_and_recovers(gpu, oracle):
+    sr = 8000
+    needle, hay = synth_case(oracle, sr, 1.0, 30.0, [4.0, 17.0], seed=41)
+    cfg = gpu.Config(chunk_size_s=10.0, overlap_length_s=1.0, distance_s=5.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    before = algo.match(hay, p)
+    assert gpu.lib().am_shutdown() == 0
+    after = algo.match(hay, p)          # plans and scratch are rebuilt on demand
+    assert [(q.start, q.height) for q in before] == [(q.start, q.height) for q in after]
+    assert [q.start for q in after] == [4 * sr, 17 * sr]
