@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--pairs-per-group", type=int, default=0)
     ap.add_argument("--k2-variant", type=int, default=-1)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (experiments)")
     ap.add_argument("--half-pipeline", action="store_true",
                     help="BASELINE config 5 precision: half-precision storage of the work matrix (not the headline)")
     args = ap.parse_args()
@@ -141,6 +142,9 @@ def main():
         am.set_option("half_pipeline", 1)
     if args.lanes:
         am.set_option("lanes", args.lanes)
+    for kv in args.opt:
+        k_, v_ = kv.split("=")
+        am.set_option(k_, int(v_))
 
     needle, algo, hays = make_inputs(am, device, args.haystacks_per_rank, rank)
     cfg = am.Config(chunk_size_s=CHUNK_S, overlap_length_s=NEEDLE_S, distance_s=480.0, prominence=0.13)
