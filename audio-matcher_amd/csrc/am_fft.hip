@@ -507,12 +507,13 @@ k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* _
     const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
     const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
     const unsigned voff = (unsigned)t * 8u;
+    const float2 wj = pl.tw2[t];
+    const float2 wc = pl.tw2[16 * (t & 31)];
     float2 x[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) x[a] = buf_load2(rrow, voff, a * 4096);   // element a*512 + t
     // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = t ----
     dif<16, false>(x);
-    const float2 wj = pl.tw2[t];
     twiddle_brev<16, false>(x, wj);
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) lds2[ap * 512 + t] = x[brev<16>(ap)];   // L1[a'][j]
@@ -522,14 +523,13 @@ k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* _
 #pragma unroll
     for (int b = 0; b < 16; ++b) x[b] = lds2[ap2 * 512 + b * 32 + c2];
     dif<16, false>(x);
-    const float2 wc = pl.tw2[16 * c2];
     twiddle_brev<16, false>(x, wc);
-    __syncthreads();
+    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
     // L2: row u = a'*16 + b' (32 points), 8-byte slot (c & 16) | ((c & 15) ^ b')
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp)
         lds2[(ap2 * 16 + bp) * 32 + ((c2 & 16) | ((c2 & 15) ^ bp))] = x[brev<16>(bp)];
-    __syncthreads();
+    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
     // ---- pass 3 over c: lane pair (u, half) holds c = half*16 + i ----
     const int u = t >> 1, half = t & 1;
     const float sgn = half ? -1.0f : 1.0f;
@@ -578,13 +578,13 @@ k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* _
         const float2 r = make_float2(fmaf(sgn, v.x, p.x), fmaf(sgn, v.y, p.y));
         lds2[u * 32 + (half * 16 + (i ^ (u & 15)))] = r;   // the pair's own row: no barrier needed before
     }
-    __syncthreads();
+    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
     // ---- inverse pass 2 over b' ----
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) x[bp] = lds2[(ap2 * 16 + bp) * 32 + ((c2 & 16) | ((c2 & 15) ^ bp))];
     twiddle_nat<16, true>(x, wc);
     dif<16, true>(x);
-    __syncthreads();
+    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[ap2 * 512 + b * 32 + c2] = x[brev<16>(b)];
     __syncthreads();
