@@ -1,0 +1,145 @@
+//! Rust binding of the C ABI in `include/audiomatch.h` and the adapter that makes it a
+//! third implementor of the reference's `CorrelateAlgo<f32>` (src/matcher/audio_matcher.rs:65-76)
+//! next to `LibConvolve` and `MyConvolve`, plus the fast replacement of `calc_chunks`
+//! (src/matcher/audio_matcher.rs:88-141).
+//!
+//! Source only: the build image has no Rust toolchain.
+
+use std::os::raw::{c_char, c_int};
+use std::time::Duration;
+
+#[repr(C)]
+pub struct AmNeedle {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct AmPeak {
+    pub start: u64,
+    pub end: u64,
+    pub height: f32,
+    pub prominence: f32,
+}
+
+#[repr(C)]
+pub struct AmMatchParams {
+    pub sr: u32,
+    pub chunk: u64,
+    pub overlap: u64,
+    pub min_prominence: f32,
+    pub min_distance: u64,
+    pub overshadow_distance_s: f64,
+    pub scale: c_int,
+}
+
+pub const AM_OK: c_int = 0;
+pub const AM_ERR_CAPACITY: c_int = 2;
+
+extern "C" {
+    pub fn am_last_error_string() -> *const c_char;
+    pub fn am_needle_create(device: c_int, needle: *const f32, n: usize, out: *mut *mut AmNeedle) -> c_int;
+    pub fn am_needle_destroy(h: *mut AmNeedle);
+    pub fn am_needle_inv_autocorr(h: *const AmNeedle, out: *mut f32) -> c_int;
+    pub fn am_correlate_len(w: usize, s: usize, mode: c_int, out_len: *mut usize) -> c_int;
+    pub fn am_correlate(
+        h: *const AmNeedle, within: *const f32, w: usize, mode: c_int, scale: c_int,
+        out: *mut f32, cap: usize, out_len: *mut usize,
+    ) -> c_int;
+    pub fn am_match(
+        h: *const AmNeedle, haystack: *const f32, len: usize, p: *const AmMatchParams,
+        out: *mut AmPeak, cap: usize, n_out: *mut usize,
+    ) -> c_int;
+}
+
+/// audio_matcher.rs:55-59
+#[derive(Debug, Clone, Copy)]
+pub enum Mode {
+    Full,
+    Same,
+    Valid,
+}
+
+fn am_err(rc: c_int) -> Box<dyn std::error::Error> {
+    let msg = unsafe { std::ffi::CStr::from_ptr(am_last_error_string()) }.to_string_lossy().into_owned();
+    format!("audiomatch error {rc}: {msg}").into()
+}
+
+/// Drop-in for `LibConvolve` (matcher/mod.rs:34).  In the reference crate this type gets
+/// `impl CorrelateAlgo<SampleType> for HipConvolve` with exactly these two methods.
+pub struct HipConvolve {
+    h: *mut AmNeedle,
+    len: usize,
+}
+unsafe impl Send for HipConvolve {}
+unsafe impl Sync for HipConvolve {}
+
+impl HipConvolve {
+    pub fn new(sample_data: Box<[f32]>) -> Result<Self, Box<dyn std::error::Error>> {
+        let mut h = std::ptr::null_mut();
+        let rc = unsafe { am_needle_create(0, sample_data.as_ptr(), sample_data.len(), &mut h) };
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        Ok(Self { h, len: sample_data.len() })
+    }
+
+    /// CorrelateAlgo::inverse_sample_auto_correlation (audio_matcher.rs:66)
+    pub fn inverse_sample_auto_correlation(&self) -> f32 {
+        let mut v = 0f32;
+        unsafe { am_needle_inv_autocorr(self.h, &mut v) };
+        v
+    }
+
+    /// CorrelateAlgo::correlate_with_sample (audio_matcher.rs:67-72)
+    pub fn correlate_with_sample(&self, within: &[f32], mode: Mode, scale: bool) -> Result<Vec<f32>, Box<dyn std::error::Error>> {
+        let m = match mode {
+            Mode::Full => 0,
+            Mode::Same => 1,
+            Mode::Valid => 2,
+        };
+        let mut n = 0usize;
+        let rc = unsafe { am_correlate_len(within.len(), self.len, m, &mut n) };
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        let mut out = vec![0f32; n];
+        let rc = unsafe { am_correlate(self.h, within.as_ptr(), within.len(), m, scale as c_int, out.as_mut_ptr(), out.len(), &mut n) };
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        Ok(out)
+    }
+
+    /// calc_chunks (audio_matcher.rs:88-141) on the GPU: peaks sorted by start, overshadowed ones removed.
+    pub fn calc_chunks(&self, sr: u16, m_samples: &[f32], scale: bool, chunk_size: Duration, overlap_length: Duration,
+                       distance: Duration, prominence: f32) -> Result<Vec<AmPeak>, Box<dyn std::error::Error>> {
+        let p = AmMatchParams {
+            sr: sr as u32,
+            chunk: (chunk_size.as_secs_f64() * sr as f64).round() as u64,       // :100
+            overlap: (overlap_length.as_secs_f64() * sr as f64).round() as u64, // :99
+            min_prominence: prominence,                                         // :227
+            min_distance: distance.as_secs() * sr as u64,                       // :228
+            overshadow_distance_s: distance.as_secs_f64(),                      // :137-138
+            scale: scale as c_int,
+        };
+        let mut buf = vec![AmPeak::default(); 256];
+        let mut n = 0usize;
+        let mut rc = unsafe { am_match(self.h, m_samples.as_ptr(), m_samples.len(), &p, buf.as_mut_ptr(), buf.len(), &mut n) };
+        if rc == AM_ERR_CAPACITY {
+            buf.resize(n, AmPeak::default());
+            rc = unsafe { am_match(self.h, m_samples.as_ptr(), m_samples.len(), &p, buf.as_mut_ptr(), buf.len(), &mut n) };
+        }
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        buf.truncate(n);
+        Ok(buf)
+    }
+}
+
+impl Drop for HipConvolve {
+    fn drop(&mut self) {
+        unsafe { am_needle_destroy(self.h) }
+    }
+}
