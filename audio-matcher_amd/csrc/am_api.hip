@@ -238,6 +238,15 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
         *logN_out = l;
         return AM_OK;
     }
+    const long long span = out_count + (long long)s - 1;
+    // The register-resident kernels exist for N = 2^21 only and are several times
+    // faster per point than the generic ones, so every problem that is not small
+    // runs on N = 2^21 as long as at least a quarter of each block is new output
+    // (needles up to ~1.5 M samples); short needles simply get a longer hop.
+    if (span > (1ll << 19) && (long long)s <= (1ll << 21) - (1ll << 19)) {
+        *logN_out = 21;
+        return AM_OK;
+    }
     int pref = min_log;
     while (pref < kLogNMax) {
         const double n = (double)((size_t)1 << pref);
@@ -245,7 +254,6 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
         ++pref;
     }
     // whole problem in one block if that is smaller
-    const long long span = out_count + (long long)s - 1;
     int single = kLogNMin;
     while (single < kLogNMax && (long long)((size_t)1 << single) < span) ++single;
     *logN_out = std::min(pref, std::max(single, min_log));

@@ -207,9 +207,7 @@ def main():
     log_n = am.get_option("log_n") or 0
     s = NEEDLE_S * SR
     if not log_n:
-        log_n = 10
-        while (2 ** log_n - s + 1) / 2 ** log_n < 0.75:
-            log_n += 1
+        log_n = 21   # the library's plan for every large problem (am_api.hip pick_log_n)
     n_fft = 2 ** log_n
     hop = n_fft - s + 1
     if hop >= 8192:
