@@ -247,6 +247,12 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
         *logN_out = 21;
         return AM_OK;
     }
+    // longer needles: N = 2^22 still has 8192-point rows, so the register row kernel
+    // (the heaviest of the three) applies; the column kernels are the generic ones
+    if (span > (1ll << 19) && (long long)s <= (1ll << 22) - (1ll << 21)) {
+        *logN_out = 22;
+        return AM_OK;
+    }
     int pref = min_log;
     while (pref < kLogNMax) {
         const double n = (double)((size_t)1 << pref);
@@ -263,7 +269,7 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
 static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
     Ctx* c = h->ctx;
     // the two K2 forms keep the spectrum in different (register-order) layouts
-    const int key = pl->dev.logN * 4 + (plan_is_r16(pl->dev) ? 1 + g_k2_variant : 0);
+    const int key = pl->dev.logN * 4 + (plan_k2_is_r16(pl->dev) ? 1 + g_k2_variant : 0);
     auto it = h->spectra.find(key);
     if (it != h->spectra.end()) { *out = it->second; return AM_OK; }
     const size_t N = (size_t)1 << pl->dev.logN;

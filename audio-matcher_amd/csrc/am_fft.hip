@@ -1026,6 +1026,8 @@ static constexpr int kR16LdsK3 = 256 * 16 * 8;
 int g_k2_variant = 0;
 
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
+// the row kernel only needs 8192-point rows; it serves any N1 (its rows are independent)
+bool plan_k2_is_r16(const PlanDev& pl) { return pl.logN2 == kR16LogN2 && pl.logN1 >= 3; }
 
 hipError_t fft_kernels_init() {
     hipError_t e;
@@ -1074,10 +1076,10 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst,
                      bool half, float hscale) {
     const dim3 grid(1u << pl.logN1, npairs);
-    if (plan_is_r16(pl) && g_k2_variant == 1) {
+    if (plan_k2_is_r16(pl) && g_k2_variant == 1) {
         hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << pl.logN1), dim3(512), kR16Lds, st, work, hc,
                            dst, pl, (unsigned)npairs);
-    } else if (plan_is_r16(pl)) {
+    } else if (plan_k2_is_r16(pl)) {
         if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
         else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
@@ -1091,10 +1093,10 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
 
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, 1);
-    if (plan_is_r16(pl) && g_k2_variant == 1) {
+    if (plan_k2_is_r16(pl) && g_k2_variant == 1) {
         hipLaunchKernelGGL(k2_rows_p512<true>, dim3(1u << pl.logN1), dim3(512), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u);
-    } else if (plan_is_r16(pl)) {
+    } else if (plan_k2_is_r16(pl)) {
         hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u, 1.0f);
     } else {

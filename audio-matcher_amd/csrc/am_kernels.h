@@ -63,6 +63,7 @@ struct ScanCfg {
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half = false);
 bool plan_is_r16(const PlanDev& pl);
+bool plan_k2_is_r16(const PlanDev& pl);
 extern int g_k2_variant;
 hipError_t fft_kernels_init();
 
