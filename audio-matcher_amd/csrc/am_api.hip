@@ -188,7 +188,10 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     int logN1 = logN - 13;
     if (logN1 < kColsLog) logN1 = kColsLog;
     if (logN1 > 9) logN1 = 9;
-    const int logN2 = logN - logN1;
+    int logN2 = logN - logN1;
+    // N = 2^22 runs on the register kernels as 256 columns x two 8192-point row halves
+    const int wide = logN == 22 ? 1 : 0;
+    if (wide) { logN1 = 8; logN2 = 13; }
     const int logLo = (logN + 1) / 2;
     const size_t n1h = (size_t)1 << (logN1 - 1), n2h = (size_t)1 << (logN2 - 1);
     const size_t nlo = (size_t)1 << logLo, nhi = (size_t)1 << (logN - logLo);
@@ -199,7 +202,7 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     fill_twiddles(host, n1h + n2h + nlo, nhi, (double)((size_t)1 << logN), (double)nlo);
     AM_HIP(hipMalloc((void**)&p.tables, host.size() * sizeof(float2)));
     AM_HIP(hipMemcpy(p.tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
-    p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo;
+    p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo; p.dev.wide = wide;
     p.dev.tw1 = p.tables;
     p.dev.tw2 = p.tables + n1h;
     p.dev.twlo = p.tables + n1h + n2h;
@@ -243,15 +246,12 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
     // faster per point than the generic ones, so every problem that is not small
     // runs on N = 2^21 as long as at least a quarter of each block is new output
     // (needles up to ~1.5 M samples); short needles simply get a longer hop.
-    if (span > (1ll << 19) && (long long)s <= (1ll << 21) - (1ll << 19)) {
-        *logN_out = 21;
-        return AM_OK;
-    }
-    // longer needles: N = 2^22 still has 8192-point rows, so the register row kernel
-    // (the heaviest of the three) applies; the column kernels are the generic ones
-    if (span > (1ll << 19) && (long long)s <= (1ll << 22) - (1ll << 21)) {
-        *logN_out = 22;
-        return AM_OK;
+    if (span > (1ll << 19)) {
+        // N = 2^21 (256 x 8192) while at least 3/4 of a block is new output; N = 2^22
+        // (256 x 2 x 8192, about 8 % dearer per point) for longer needles, up to 3 M
+        // samples; beyond that the generic kernels at N = 2^23
+        if ((long long)s <= (1ll << 19)) { *logN_out = 21; return AM_OK; }
+        if ((long long)s <= (1ll << 22) - (1ll << 20)) { *logN_out = 22; return AM_OK; }
     }
     int pref = min_log;
     while (pref < kLogNMax) {
@@ -322,10 +322,10 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
-        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
         if (plan_is_r16(pl->dev) && (hop % kTile) == 0) {
             if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-            if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
+            if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;
             scan.stats32 = (float2*)c->stats32.p;
             scan.wflags = (unsigned char*)c->wflags.p;
             scan.theta = scan_req->theta;
@@ -333,12 +333,12 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
             scan.seg_d = scan_req->seg_d;
             scan.inv_c = scan.seg_c > 0 ? 1.0 / (double)scan.seg_c : 0.0;
             scan_req->fused = true;
-            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
         }
     }
     // half-precision storage of the work matrix: K2 normalises by the needle
     // energy (times a fixed gain) so that stored values sit mid-range in f16
-    const bool half = g_opt_half && plan_is_r16(pl->dev) && g_k2_variant == 0;
+    const bool half = g_opt_half && plan_is_r16(pl->dev) && !pl->dev.wide && g_k2_variant == 0;
     const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
     const float k3scale = half ? factor / hscale : factor;
     Job job{};
@@ -640,13 +640,13 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     const bool fused = plan_is_r16(pl->dev) && (hop % kTile) == 0;
     if (fused) {
         if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-        if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
+        if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;
     }
     Job job{};
     job.src = d_hay; job.src_len = (long long)len; job.lead = 0; job.src_kind = src_kind;
     job.dst = (float*)c->scores.p; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
     job.first_pair = 0;
-    const bool half = g_opt_half && plan_is_r16(pl->dev) && g_k2_variant == 0;
+    const bool half = g_opt_half && plan_is_r16(pl->dev) && !pl->dev.wide && g_k2_variant == 0;
     { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)npairs, (float2*)c->work.p, pl->dev, half)); }
     for (size_t k = 0; k < nn; ++k) {
         am_needle* h = needles[k];
@@ -655,12 +655,12 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         scan.seg_c = (long long)p->chunk;
         scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
         scan.fused = fused;
-        scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+        scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
         ScanCfg cfg{};
         if (fused) {
             cfg.stats32 = (float2*)c->stats32.p; cfg.wflags = (unsigned char*)c->wflags.p; cfg.theta = scan.theta;
             cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
-            scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+            scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
         }
         const float factor = scale_factor(h, p->scale, 1);
         const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;

@@ -218,26 +218,17 @@ __device__ __forceinline__ float2 load2_padded(const void* __restrict__ src, lon
 // K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
 // FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
 // holds frequency k1 in natural order.
-template <int KIND, bool HALF>
-__global__ void __launch_bounds__(256, 3)
-k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
-    extern __shared__ float4 lds4[];
-    const int t = threadIdx.x;
-    const int hi = t >> 4, cp = t & 15;
-    const int n2_0 = blockIdx.x << kColsLog;
-    const int pair = job.first_pair + blockIdx.y;
-    const long long blkA = 2ll * pair, blkB = blkA + 1;
-    const bool validB = blkB < job.nblocks;
+// One column tile of K1: loads rows n1 = a*16 + b of 2 adjacent columns (sample
+// index n1 * in_stride + col in both packed blocks), 256-point column FFT (two
+// passes with one LDS exchange), pipeline twiddle W_N^(col*k1).  On return
+// x0/x1[brev(b')] hold row k1 = hi + 16*b' of columns col, col+1.
+template <int KIND>
+__device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float2* lds2, long long col, int in_stride,
+                                        int hi, int cp, long long baseA, long long baseB, bool validB, bool fast,
+                                        float2 (&x0)[16], float2 (&x1)[16]) {
     const long long N = 1ll << pl.logN;
-    const long long baseA = blkA * job.hop - job.lead;
-    const long long baseB = blkB * job.hop - job.lead;
-    const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
-                      baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
-    float2 x0[16], x1[16];
-    // pass 1 ownership: b = hi (n1 = a*16 + b), columns 2cp, 2cp+1
-    const long long col = n2_0 + 2 * cp;
-    // every table lookup this workgroup needs, issued before the samples so that
-    // their latency overlaps the streaming loads: W_256^b for the pass boundary and
+    // every table lookup this tile needs, issued before the samples so that their
+    // latency overlaps the streaming loads: W_256^b for the pass boundary and
     // W_N^(n2*a'), W_N^(16*n2) for the pipeline twiddle (k1 = a' + 16*b', a' = hi)
     const unsigned maskN = (unsigned)(N - 1);
     const float2 w256 = pl.tw1[hi];
@@ -245,10 +236,11 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     const float2 base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)hi) & maskN);
     const float2 step0 = tw_big(pl, ((unsigned)col * 16u) & maskN);
     const float2 step1 = tw_big(pl, (((unsigned)col + 1u) * 16u) & maskN);
+    // pass 1 ownership: b = hi (n1 = a*16 + b), columns col, col+1
     if (fast) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const long long off = (long long)(a * 16 + hi) * kN2 + col;
+            const long long off = (long long)(a * 16 + hi) * in_stride + col;
             const float2 va = load_sample2<KIND>(job.src, baseA + off), vb = load_sample2<KIND>(job.src, baseB + off);
             x0[a] = make_float2(va.x, vb.x);
             x1[a] = make_float2(va.y, vb.y);
@@ -256,7 +248,7 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     } else {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            const long long n = (long long)(a * 16 + hi) * in_stride + col;
             const float2 va = load2_padded<KIND>(job.src, baseA + n, job.src_len);
             const float2 vb = validB ? load2_padded<KIND>(job.src, baseB + n, job.src_len) : make_float2(0.f, 0.f);
             x0[a] = make_float2(va.x, vb.x);
@@ -270,7 +262,6 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     // Exchange between the two passes, one column of the pair at a time so that a
     // workgroup needs 34 KB of LDS (row stride 17 keeps the 8-byte reads of rows
     // 16 apart on disjoint banks): pass 2 owns a' = hi, b = 0..15.
-    float2* lds2 = reinterpret_cast<float2*>(lds4);
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) lds2[(ap * 16 + hi) * 17 + cp] = x0[brev<16>(ap)];
     __syncthreads();
@@ -287,6 +278,25 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     // k1 = a' + 16*b';  W_N^(n2*k1) = W_N^(n2*a') * (W_N^(16*n2))^b'
     twiddle_chain<16, false, true>(x0, base0, step0);
     twiddle_chain<16, false, true>(x1, base1, step1);
+}
+
+template <int KIND, bool HALF>
+__global__ void __launch_bounds__(256, 3)
+k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
+    extern __shared__ float4 lds4[];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    const int n2_0 = blockIdx.x << kColsLog;
+    const int pair = job.first_pair + blockIdx.y;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const bool validB = blkB < job.nblocks;
+    const long long N = 1ll << pl.logN;
+    const long long baseA = blkA * job.hop - job.lead;
+    const long long baseB = blkB * job.hop - job.lead;
+    const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
+                      baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
+    float2 x0[16], x1[16];
+    k1_tile<KIND>(job, pl, reinterpret_cast<float2*>(lds4), (long long)n2_0 + 2 * cp, kN2, hi, cp, baseA, baseB, validB, fast, x0, x1);
     if (HALF) {
         uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
 #pragma unroll
@@ -302,6 +312,48 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
         const size_t k1 = (size_t)(hi + 16 * bp);
         out4[k1 * (kN2 / 2)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
                                            x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
+    }
+}
+
+// K1 for N = 2^22 = 256 x 16384: the 16384-point rows are split by one radix-2
+// stage into two 8192-point rows (even / odd frequencies) that K2 handles as
+// independent rows.  One workgroup transforms the two column tiles m and m + 8192,
+// forms s = A + B and d = (A - B) * W_16384^m and stores them as work rows
+// 2*k1 and 2*k1 + 1.
+template <int KIND>
+__global__ void __launch_bounds__(256, 2)
+k1_cols_fwd_w16(Job job, float2* __restrict__ work, PlanDev pl) {
+    extern __shared__ float4 lds4[];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    const int m_0 = blockIdx.x << kColsLog;
+    const int pair = job.first_pair + blockIdx.y;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const bool validB = blkB < job.nblocks;
+    const long long N = 1ll << pl.logN;
+    const long long baseA = blkA * job.hop - job.lead;
+    const long long baseB = blkB * job.hop - job.lead;
+    const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
+                      baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
+    const long long m = (long long)m_0 + 2 * cp;
+    const unsigned maskN = (unsigned)(N - 1);
+    // W_16384^m = W_N^(256 m)
+    const float2 wd0 = tw_big(pl, ((unsigned)m * 256u) & maskN);
+    const float2 wd1 = tw_big(pl, (((unsigned)m + 1u) * 256u) & maskN);
+    float2 a0[16], a1[16], x0[16], x1[16];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    k1_tile<KIND>(job, pl, lds2, m, 2 * kN2, hi, cp, baseA, baseB, validB, fast, a0, a1);
+    __syncthreads();   // the LDS tile is reused
+    k1_tile<KIND>(job, pl, lds2, m + kN2, 2 * kN2, hi, cp, baseA, baseB, validB, fast, x0, x1);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + m_0) + cp;
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) {
+        const int i = brev<16>(bp);
+        const float2 s0 = cadd(a0[i], x0[i]), s1 = cadd(a1[i], x1[i]);
+        const float2 d0 = cmul(csub(a0[i], x0[i]), wd0), d1 = cmul(csub(a1[i], x1[i]), wd1);
+        const size_t k1 = (size_t)(hi + 16 * bp);
+        out4[(2 * k1) * (kN2 / 2)] = make_float4(s0.x, s0.y, s1.x, s1.y);
+        out4[(2 * k1 + 1) * (kN2 / 2)] = make_float4(d0.x, d0.y, d1.x, d1.y);
     }
 }
 
@@ -662,42 +714,17 @@ __device__ __forceinline__ float group16_max(float v) {
 // K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
-template <bool HALF>
-__global__ void __launch_bounds__(256, 3)
-k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
-    extern __shared__ float4 lds4[];
-    __shared__ int vote[2];
-    const int t = threadIdx.x;
-    if (t < 2) vote[t] = 0;
+// Everything K3 does with one column tile once its rows k1 = hi + 16*b' (natural
+// b' order, columns col, col+1) are in registers: conjugate pipeline twiddle,
+// inverse 256-point column FFT, scaling, fused score scan, conditional raw-score
+// store.  Output index of row n1, column c is n1 * out_stride + c.
+__device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2, int* vote,
+                                        int n2_0, int out_stride, int t, long long blkA, long long blkB,
+                                        float out_scale, float2 (&x0)[16], float2 (&x1)[16]) {
     const int hi = t >> 4, cp = t & 15;
-    // XCD-aware placement (speed only): the 16 adjacent column tiles that share
-    // one 128-byte line of stats32 run on the same XCD, so the line is merged in
-    // that L2 before it is written back.  256 tiles per pair = 8 XCDs x 2 x 16.
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
-    const int n2_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
-    const int pair = job.first_pair + (int)slot;
-    const long long blkA = 2ll * pair, blkB = blkA + 1;
     const long long N = 1ll << pl.logN;
     const long long col = n2_0 + 2 * cp;
-    float2 x0[16], x1[16];
-    if (HALF) {
-        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
-#pragma unroll
-        for (int bp = 0; bp < 16; ++bp) {
-            const uint2 v = in2[(size_t)(hi + 16 * bp) * (kN2 / 2)];
-            x0[bp] = unpack_h2(v.x);
-            x1[bp] = unpack_h2(v.y);
-        }
-    } else {
-        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
-#pragma unroll
-        for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
-            const float4 v = in4[(size_t)(hi + 16 * bp) * (kN2 / 2)];
-            x0[bp] = make_float2(v.x, v.y);
-            x1[bp] = make_float2(v.z, v.w);
-        }
-    }
+    if (t < 2) vote[t] = 0;
     const unsigned maskN = (unsigned)(N - 1);
     const float2 w256 = pl.tw1[hi];
     {
@@ -713,7 +740,6 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     dif<16, true>(x1);
     // exchange, one column of the pair at a time (32 KB of LDS per workgroup);
     // afterwards ownership is b = hi, a' = 0..15
-    float2* lds2 = reinterpret_cast<float2*>(lds4);
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[(hi * 16 + b) * 16 + cp] = x0[brev<16>(b)];
     __syncthreads();
@@ -752,7 +778,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
             // the block that holds the end of the score array)
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                const int run = (a * 16 + hi) * kN2 + n2_0;
+                const int run = (a * 16 + hi) * out_stride + n2_0;
                 mnA[a] = fminf(sa0[a], sa1[a]); mxA[a] = fmaxf(sa0[a], sa1[a]);
                 mnB[a] = fminf(sb0[a], sb1[a]); mxB[a] = fmaxf(sb0[a], sb1[a]);
                 tmaxA = run < limAi ? fmaxf(tmaxA, mxA[a]) : tmaxA;
@@ -761,7 +787,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         } else {
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                const int n = (a * 16 + hi) * kN2 + (int)col;
+                const int n = (a * 16 + hi) * out_stride + (int)col;
                 const bool a0v = n < limAi, a1v = n + 1 < limAi, b0v = n < limBi, b1v = n + 1 < limBi;
                 mnA[a] = fminf(a0v ? sa0[a] : FLT_MAX, a1v ? sa1[a] : FLT_MAX);
                 mxA[a] = fmaxf(a0v ? sa0[a] : -FLT_MAX, a1v ? sa1[a] : -FLT_MAX);
@@ -773,7 +799,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         }
         // raw scores leave the chip only for tiles that can matter to the peak
         // pick: some score >= theta, or a run that straddles a chunk edge
-        const long long rowrun = (long long)t * kN2 + n2_0;   // thread t checks row n1 = t
+        const long long rowrun = (long long)t * out_stride + n2_0;   // thread t checks row n1 = t
         const bool edgeA = rowrun < limA && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         const bool edgeB = rowrun < limB && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         // one block-wide vote for both blocks: per-wave ballots into two LDS words
@@ -786,20 +812,20 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         wantB = vote[1] != 0;
         if (t == 0 && scan.wflags != nullptr) {
             const unsigned tile = (unsigned)n2_0 >> kColsLog;
-            scan.wflags[blkA * (kN2 >> kColsLog) + tile] = wantA ? 1 : 0;
-            if (blkB < job.nblocks) scan.wflags[blkB * (kN2 >> kColsLog) + tile] = wantB ? 1 : 0;
+            scan.wflags[blkA * (out_stride >> kColsLog) + tile] = wantA ? 1 : 0;
+            if (blkB < job.nblocks) scan.wflags[blkB * (out_stride >> kColsLog) + tile] = wantB ? 1 : 0;
         }
         const float rmnA = treduce16<false>(mnA, cp), rmxA = treduce16<true>(mxA, cp);
         const float rmnB = treduce16<false>(mnB, cp), rmxB = treduce16<true>(mxB, cp);
         // lane cp now owns the summary of row n1 = cp*16 + hi
-        const long long run = (long long)(cp * 16 + hi) * kN2 + n2_0;
+        const long long run = (long long)(cp * 16 + hi) * out_stride + n2_0;
         if (run < limA) scan.stats32[(outA + run) >> 5] = make_float2(rmnA, rmxA);
         if (run < limB) scan.stats32[(outB + run) >> 5] = make_float2(rmnB, rmxB);
     }
     if (wantA) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            const long long n = (long long)(a * 16 + hi) * out_stride + col;
             // hop and out offsets are even whenever this kernel is used, so a pair is
             // valid or invalid as a whole except at the very end of the score array
             if (dst8 && n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(sa0[a], sa1[a]);
@@ -812,7 +838,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     if (wantB) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * 16 + hi) * kN2 + col;
+            const long long n = (long long)(a * 16 + hi) * out_stride + col;
             if (dst8 && n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(sb0[a], sb1[a]);
             else {
                 if (n < limB) job.dst[outB + n] = sb0[a];
@@ -820,6 +846,78 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
             }
         }
     }
+}
+
+template <bool HALF>
+__global__ void __launch_bounds__(256, 3)
+k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    __shared__ int vote[2];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    // XCD-aware placement (speed only): the 16 adjacent column tiles that share
+    // one 128-byte line of stats32 run on the same XCD, so the line is merged in
+    // that L2 before it is written back.  256 tiles per pair = 8 XCDs x 2 x 16.
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
+    const int n2_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
+    const int pair = job.first_pair + (int)slot;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    float2 x0[16], x1[16];
+    if (HALF) {
+        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bp = 0; bp < 16; ++bp) {
+            const uint2 v = in2[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+            x0[bp] = unpack_h2(v.x);
+            x1[bp] = unpack_h2(v.y);
+        }
+    } else {
+        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
+            const float4 v = in4[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+            x0[bp] = make_float2(v.x, v.y);
+            x1[bp] = make_float2(v.z, v.w);
+        }
+    }
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), vote, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+}
+
+// K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
+// the inverse 8192-point transforms e / o of the even / odd row frequencies;
+// y[m] = e + conj(W_16384^m) o and y[m + 8192] = e - conj(W_16384^m) o give the two
+// column tiles m and m + 8192, which then go through the same tile code.
+__global__ void __launch_bounds__(256, 2)
+k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    __shared__ int vote[2];
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
+    const int m_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
+    const int pair = job.first_pair + (int)slot;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const long long N = 1ll << pl.logN;
+    const unsigned maskN = (unsigned)(N - 1);
+    const unsigned m = (unsigned)m_0 + 2u * (unsigned)cp;
+    const float2 wd0 = tw_big(pl, (m * 256u) & maskN);
+    const float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
+    float2 e0[16], e1[16], o0[16], o1[16];
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + m_0) + cp;
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) {
+        const size_t k1 = (size_t)(hi + 16 * bp);
+        const float4 ve = in4[(2 * k1) * (kN2 / 2)], vo = in4[(2 * k1 + 1) * (kN2 / 2)];
+        const float2 p0 = cmulc(make_float2(vo.x, vo.y), wd0), p1 = cmulc(make_float2(vo.z, vo.w), wd1);
+        e0[bp] = cadd(make_float2(ve.x, ve.y), p0); o0[bp] = csub(make_float2(ve.x, ve.y), p0);
+        e1[bp] = cadd(make_float2(ve.z, ve.w), p1); o1[bp] = csub(make_float2(ve.z, ve.w), p1);
+    }
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    k3_tile(job, pl, scan, lds2, vote, m_0, 2 * kN2, t, blkA, blkB, out_scale, e0, e1);
+    __syncthreads();   // LDS tile and vote words are reused
+    k3_tile(job, pl, scan, lds2, vote, m_0 + kN2, 2 * kN2, t, blkA, blkB, out_scale, o0, o1);
 }
 
 // ===========================================================================
@@ -1043,6 +1141,9 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k1_cols_fwd_r16<1, false>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<0, true>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<1, true>), kR16LdsK1)
+    AM_SET_LDS(k1_cols_fwd_w16<0>, kR16LdsK1)
+    AM_SET_LDS(k1_cols_fwd_w16<1>, kR16LdsK1)
+    AM_SET_LDS(k3_cols_inv_w16, kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_r16<false>, kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_r16<true>, kR16LdsK3)
     AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
@@ -1057,7 +1158,10 @@ hipError_t fft_kernels_init() {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     const bool pcm = job.src_kind == 1;
-    if (plan_is_r16(pl)) {
+    if (plan_is_r16(pl) && pl.wide) {
+        if (pcm) hipLaunchKernelGGL(k1_cols_fwd_w16<1>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        else hipLaunchKernelGGL(k1_cols_fwd_w16<0>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
+    } else if (plan_is_r16(pl)) {
         if (half) {
             if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
             else hipLaunchKernelGGL((k1_cols_fwd_r16<0, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
@@ -1077,12 +1181,12 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
                      bool half, float hscale) {
     const dim3 grid(1u << pl.logN1, npairs);
     if (plan_k2_is_r16(pl) && g_k2_variant == 1) {
-        hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << pl.logN1), dim3(512), kR16Lds, st, work, hc,
+        hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(512), kR16Lds, st, work, hc,
                            dst, pl, (unsigned)npairs);
     } else if (plan_k2_is_r16(pl)) {
-        if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+        if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
-        else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+        else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, hc,
                                 dst, pl, (unsigned)npairs, 1.0f);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
@@ -1094,10 +1198,10 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, 1);
     if (plan_k2_is_r16(pl) && g_k2_variant == 1) {
-        hipLaunchKernelGGL(k2_rows_p512<true>, dim3(1u << pl.logN1), dim3(512), kR16Lds, st, work, (const float2*)nullptr,
+        hipLaunchKernelGGL(k2_rows_p512<true>, dim3(1u << (pl.logN1 + pl.wide)), dim3(512), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u);
     } else if (plan_k2_is_r16(pl)) {
-        hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
+        hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u, 1.0f);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
@@ -1110,7 +1214,10 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
-    if (plan_is_r16(pl)) {
+    if (plan_is_r16(pl) && pl.wide) {
+        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+                           pl, out_scale, scan);
+    } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                                      pl, out_scale, scan);
         else hipLaunchKernelGGL(k3_cols_inv_r16<false>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
