@@ -886,38 +886,41 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 
 // K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
 // the inverse 8192-point transforms e / o of the even / odd row frequencies;
-// y[m] = e + conj(W_16384^m) o and y[m + 8192] = e - conj(W_16384^m) o give the two
-// column tiles m and m + 8192, which then go through the same tile code.
-__global__ void __launch_bounds__(256, 2)
+// y[m] = e + conj(W_16384^m) o and y[m + 8192] = e - conj(W_16384^m) o are the two
+// column tiles m and m + 8192.  Each workgroup produces ONE of the two tiles (so it
+// keeps the register footprint and occupancy of the 2^21 kernel) and therefore
+// reads both row halves; the two workgroups of a tile pair are adjacent on one XCD,
+// so the second read of a line is served by that L2.
+__global__ void __launch_bounds__(256, 3)
 k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     __shared__ int vote[2];
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
+    const unsigned h = seq & 1u, rest = seq >> 1;
+    const unsigned slot = rest >> 5, half = (rest >> 4) & 1u, tl = rest & 15u;
     const int m_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
     const long long blkA = 2ll * pair, blkB = blkA + 1;
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned m = (unsigned)m_0 + 2u * (unsigned)cp;
-    const float2 wd0 = tw_big(pl, (m * 256u) & maskN);
-    const float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
-    float2 e0[16], e1[16], o0[16], o1[16];
+    const float sgn = h ? -1.0f : 1.0f;
+    float2 wd0 = tw_big(pl, (m * 256u) & maskN);
+    float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
+    wd0 = make_float2(sgn * wd0.x, -sgn * wd0.y);   // +-conj(W_16384^m)
+    wd1 = make_float2(sgn * wd1.x, -sgn * wd1.y);
+    float2 x0[16], x1[16];
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + m_0) + cp;
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
         const size_t k1 = (size_t)(hi + 16 * bp);
         const float4 ve = in4[(2 * k1) * (kN2 / 2)], vo = in4[(2 * k1 + 1) * (kN2 / 2)];
-        const float2 p0 = cmulc(make_float2(vo.x, vo.y), wd0), p1 = cmulc(make_float2(vo.z, vo.w), wd1);
-        e0[bp] = cadd(make_float2(ve.x, ve.y), p0); o0[bp] = csub(make_float2(ve.x, ve.y), p0);
-        e1[bp] = cadd(make_float2(ve.z, ve.w), p1); o1[bp] = csub(make_float2(ve.z, ve.w), p1);
+        x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
+        x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
     }
-    float2* lds2 = reinterpret_cast<float2*>(lds4);
-    k3_tile(job, pl, scan, lds2, vote, m_0, 2 * kN2, t, blkA, blkB, out_scale, e0, e1);
-    __syncthreads();   // LDS tile and vote words are reused
-    k3_tile(job, pl, scan, lds2, vote, m_0 + kN2, 2 * kN2, t, blkA, blkB, out_scale, o0, o1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), vote, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -1215,7 +1218,7 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl) && pl.wide) {
-        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * 2u * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                            pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
