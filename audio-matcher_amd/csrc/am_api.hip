@@ -518,6 +518,8 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     seg_off[n_hay] = (int)segs.size();
     const size_t nsegs = segs.size();
     if (nsegs == 0) return AM_OK;
+    if (max_segs > (size_t)1 << 18 || nsegs > (size_t)1 << 24)
+        return fail(AM_ERR_INVALID_ARG, "chunk size too small for this haystack (more than 2^18 chunks)");
     int rc;
     const size_t seg_bytes = sizeof(Segment) * nsegs, hdr_bytes = sizeof(SegHeader) * nsegs;
     if ((rc = c->scores.ensure(max_scores * sizeof(float)))) return rc;
