@@ -104,7 +104,7 @@ struct Ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, work2, scores, stats, stats32, wflags, segs, hdr, peaks, counts, io_in, io_out, sum;
+    DevBuf work, work2, scores, stats, stats32, wflags, segs, hdr, peaks, io_in, io_out, sum;
     HostBuf pinned;
     // profiling
     bool prof = false;
@@ -1088,7 +1088,7 @@ int am_shutdown(void) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs, &c->hdr,
-                          &c->peaks, &c->counts, &c->io_in, &c->io_out, &c->sum})
+                          &c->peaks, &c->io_in, &c->io_out, &c->sum})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);

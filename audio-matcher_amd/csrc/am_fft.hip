@@ -23,7 +23,9 @@
 //                    -> scores of block 2g+1, plus a (min,max) summary per 32
 //                    scores for the peak pick.
 //
-// Two implementations of each kernel exist:
+// Three families of kernels exist:
+//   *_w16 : K1/K3 for N = 2^22 = 256 x (2 x 8192) (longer needles): one radix-2
+//           stage splits each 16384-point row into two 8192-point rows for K2.
 //   *_r16 : the production shape N1 = 256, N2 = 8192 (N = 2^21).  Radix-16/32
 //           butterflies held in VGPRs, LDS used only for the exchanges between
 //           passes (conflict-free 16-byte accesses, XOR-swizzled rows), 16-byte
@@ -700,21 +702,11 @@ __device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, lo
     return mod_recip(hi2, c, inv_c) <= 31;
 }
 
-__device__ __forceinline__ float group16_min(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
 // K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
-// Everything K3 does with one column tile once its rows k1 = hi + 16*b' (natural
+//
+// k3_tile: everything K3 does with one column tile once its rows k1 = hi + 16*b' (natural
 // b' order, columns col, col+1) are in registers: conjugate pipeline twiddle,
 // inverse 256-point column FFT, scaling, fused score scan, conditional raw-score
 // store.  Output index of row n1, column c is n1 * out_stride + c.
