@@ -90,3 +90,23 @@ def test_find_peaks_random_vs_oracle(gpu, oracle):
             continue
         got = [(p.start, p.end, p.height, p.prominence) for p in gpu.find_peaks(y, prom, dist)]
         assert got == exp, (trial, n, prom, dist)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_wide_plan(gpu, oracle, seed):
+    """Needles of 0.6-1.2 M samples select N = 2^22 (256 x 2 x 8192 kernels), incl. hits on chunk edges."""
+    rng = np.random.default_rng(3000 + seed)
+    sr = 44100
+    s = int(rng.integers(600_000, 1_200_000))
+    h = int(rng.integers(14_000_000, 18_000_000))
+    needle, hay = build_case(oracle, rng, sr, s, h, int(rng.integers(1, 4)))
+    chunk = int(rng.integers(4_000_000, 6_000_000)) | 1
+    # one more hit a few samples after a chunk start
+    off = chunk + int(rng.integers(1, 40))
+    hay[off:off + s] += needle
+    compare(gpu, oracle, needle, hay, sr, chunk, s, 0.13, float(rng.choice([5.0, 480.0])))
+    # level 1 on the same plan
+    win = hay[: s + 3_000_000]
+    got = gpu.HipConvolve(needle).correlate_with_sample(win, gpu.Mode.Valid, True)
+    ref = oracle.correlate(win, needle, oracle.MODE_VALID, oracle.SCALE_LIB)
+    assert np.abs(got - ref).max() < TOL
