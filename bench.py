@@ -153,7 +153,7 @@ def main():
 
     def step(i):
         k, buf = hays[i % len(hays)]
-        return k, algo.match_device(buf.ptr, h, params)
+        return k, algo.match_device(buf.ptr, h, params, cap=64)
 
     def sync():
         am._check(am.lib().am_device_synchronize(device))
