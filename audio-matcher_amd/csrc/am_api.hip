@@ -731,13 +731,16 @@ static int check_needle(const am_needle* h) {
 static int create_needle_common(Ctx* c, float* d_needle, size_t n, am_needle** out) {
     am_needle* h = new am_needle();
     h->ctx = c; h->d_needle = d_needle; h->n = n;
-    int rc = c->sum.ensure(sizeof(double));
+    const int parts = sumsq_parts((long long)n);
+    int rc = c->sum.ensure(sizeof(double) * (size_t)parts);
     if (rc) { (void)hipFree(d_needle); delete h; return rc; }
     hipError_t e = launch_sumsq(c->stream, d_needle, (long long)n, (double*)c->sum.p);
-    double ss = 0.0;
+    std::vector<double> part((size_t)parts, 0.0);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(&ss, c->sum.p, sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(part.data(), c->sum.p, sizeof(double) * (size_t)parts, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { (void)hipFree(d_needle); delete h; return hip_fail(e, "needle energy"); }
+    double ss = 0.0;
+    for (double v : part) ss += v;
     h->inv_autocorr = (float)(1.0 / ss);   // audio_matcher.rs:321-329
     *out = h;
     return AM_OK;
@@ -783,7 +786,11 @@ int am_needle_create_device(int device, const float* d_needle, size_t n, am_need
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     float* d = nullptr;
     AM_HIP(hipMalloc((void**)&d, n * sizeof(float)));
-    hipError_t e = hipMemcpy(d, d_needle, n * sizeof(float), hipMemcpyDeviceToDevice);
+    // On the context's stream: a device-to-device hipMemcpy returns before the copy
+    // has run and the null stream does not order with this non-blocking stream, so
+    // the energy reduction below could otherwise read a partly copied needle.
+    hipError_t e = hipMemcpyAsync(d, d_needle, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(needle d2d)"); }
     return create_needle_common(c, d, n, out);
 }

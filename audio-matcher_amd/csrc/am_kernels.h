@@ -91,7 +91,9 @@ struct SparseScores {
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp);
-hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_out);
+// writes sumsq_parts(n) partial sums (one per workgroup) to d_parts
+int sumsq_parts(long long n);
+hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts);
 hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
                         long long n, float amp);
 hipError_t launch_axpy(hipStream_t st, float* dst, const float* src, long long n, float gain);

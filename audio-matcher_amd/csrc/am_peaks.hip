@@ -407,7 +407,9 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
 
 // ---------------------------------------------------------------------------
 // sum of squares in f64 (CorrelateAlgo::inverse_sample_auto_correlation,
-// audio_matcher.rs:321-329: element 0 of the needle's autocorrelation)
+// audio_matcher.rs:321-329: element 0 of the needle's autocorrelation).  One
+// partial sum per workgroup; the host adds them in index order, so the result
+// does not depend on the order in which workgroups finish.
 __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, long long n, double* out) {
     __shared__ double part[4];
     double acc = 0.0;
@@ -419,7 +421,7 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x,
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
@@ -488,10 +490,10 @@ hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const f
     return hipGetLastError();
 }
 
-hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_out) {
-    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(double), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, d_out);
+int sumsq_parts(long long n) { return grid_for(n); }
+
+hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, d_parts);
     return hipGetLastError();
 }
 

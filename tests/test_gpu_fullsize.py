@@ -71,10 +71,32 @@ def test_score_checksum_full_vector(full, oracle):
     expect_alt = float(np.sum(n_host.astype(np.float64) * np.where(idx & 1, -1.0, 1.0) * (alt[idx + J] - alt[idx]))) / e
     got_alt = float(np.sum(scores.astype(np.float64) * w))
     assert abs(got_alt - expect_alt) < 1e-6 * J
-    # spot values against the direct definition
-    for j in (0, 1, 777_777, plant_offsets(0)[2], J - 1):
-        direct = float(np.dot(h_host[j:j + S].astype(np.float64), n_host.astype(np.float64))) / e
-        assert abs(float(scores[j]) - direct) < 1e-4
+    # the needle energy behind every scaled score (audio_matcher.rs:321-329)
+    assert abs(algo.inverse_sample_auto_correlation() * e - 1.0) < 1e-6
+    # spot values against the direct definition: both ends, block interiors, every plant
+    n64 = n_host.astype(np.float64)
+    for j in (0, 1, 777_777, 1_655_807, 1_655_808, J - 2, J - 1, *plant_offsets(0)):
+        direct = float(np.dot(h_host[j:j + S].astype(np.float64), n64)) / e
+        assert abs(float(scores[j]) - direct) < 1e-4, j
+
+
+def test_needle_from_device_memory_is_complete(full):
+    """Regression: the needle handle copies a device buffer the caller may have just
+    written; its energy (and with it every scaled score) must not depend on timing.
+    A fresh source buffer per round keeps the copy on the cold path."""
+    gpu, needle, algo, hay, p = full
+    n = 4_000_000
+    src_host = np.random.default_rng(3).uniform(-0.25, 0.25, n).astype(np.float32)
+    expect = 1.0 / float(np.sum(src_host.astype(np.float64) ** 2))
+    got = set()
+    for _ in range(20):
+        src = gpu.DeviceBuffer.from_numpy(0, src_host)
+        a = gpu.HipConvolve.from_device(0, src.ptr, n)
+        got.add(a.inverse_sample_auto_correlation())
+        a.close()
+        src.free()
+    assert len(got) == 1                      # bitwise reproducible
+    assert abs(got.pop() / expect - 1.0) < 1e-6
 
 
 def test_batch_equals_singles_full_size(full):

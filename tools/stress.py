@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Repeat the full-size correlation / match many times and compare every result
+bit for bit with the first one (hunting for intermittent data races)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-matcher_amd", "python"))
+import audiomatch_amd as am   # noqa: E402
+
+SR = 44100
+S = 10 * SR
+H = 3600 * SR
+
+
+def plant_offsets(k):
+    return [600 * SR * m + 30 * SR + 17 * k + 1234 for m in range(6)]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    mix = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=")
+        am.set_option(k, int(v))
+    needle = am.synth_uniform_device(0, S, seed=1, stream=0)
+    algo = am.HipConvolve.from_device(0, needle.ptr, S)
+    hay = am.synth_uniform_device(0, H, seed=1, stream=1)
+    for t in plant_offsets(0):
+        am.axpy_device(0, hay, t, needle.ptr, S, 1.0)
+    cfg = am.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=480.0, prominence=0.13)
+    p = cfg.params(SR, am.Scale.LIB)
+    J = H - S + 1
+    out = am.DeviceBuffer(0, 4 * J)
+    n = C.c_size_t(0)
+
+    def corr():
+        am._check(am.lib().am_correlate_device(algo._h, hay.ptr, H, int(am.Mode.Valid), int(am.Scale.LIB),
+                                               out.ptr, J, C.byref(n)))
+        return out.to_numpy(np.float32, J)
+
+    key = lambda r: [(q.start, q.end, q.height, q.prominence) for q in r]
+    ref = corr()
+    mref = key(algo.match_device(hay.ptr, H, p))
+    bad = 0
+    for it in range(iters):
+        if mix:
+            m = key(algo.match_device(hay.ptr, H, p))
+            if m != mref:
+                bad += 1
+                print("iter %d: match differs: %s" % (it, m), flush=True)
+            if mix > 1:
+                k = 12345
+                algo.match_device(hay.ptr + 4 * k, H - k, p)
+        a = corr()
+        if not np.array_equal(a, ref):
+            bad += 1
+            d = np.nonzero(a != ref)[0]
+            err = np.abs(a[d].astype(np.float64) - ref[d])
+            print("iter %d: %d scores differ, idx %d..%d, max |diff| %.3e at %d" %
+                  (it, d.size, d[0], d[-1], err.max(), d[int(np.argmax(err))]), flush=True)
+            hop = 1655808
+            blocks = np.unique(d // hop)
+            print("   blocks touched:", blocks[:20], "n_blocks", blocks.size, flush=True)
+        if it % 20 == 0:
+            print("iter", it, "bad so far", bad, flush=True)
+    print("done: %d iterations, %d mismatches" % (iters, bad))
+
+
+if __name__ == "__main__":
+    main()
