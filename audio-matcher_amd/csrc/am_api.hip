@@ -78,10 +78,11 @@ struct DevBuf {
 struct HostBuf {
     void* p = nullptr;
     size_t cap = 0;
+    unsigned flags = hipHostMallocDefault;
     int ensure(size_t bytes) {
         if (bytes <= cap) return AM_OK;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(&p, bytes, flags);
         if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipHostMalloc"); }
         cap = bytes;
         return AM_OK;
@@ -104,8 +105,14 @@ struct Ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, work2, scores, stats, stats32, wflags, segs, hdr, peaks, io_in, io_out, sum;
+    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum;
     HostBuf pinned;
+    // Per-chunk result headers live in coherent pinned host memory that the peak
+    // kernel writes directly (a few KB per haystack): no device-to-host copy
+    // sits between the last kernel and the host's wake-up.
+    HostBuf hdr;
+    // the chunk list currently resident in `segs` (re-uploaded only when it changes)
+    std::vector<Segment> segs_resident;
     // profiling
     bool prof = false;
     std::vector<ProfRec> pending;
@@ -131,6 +138,7 @@ static int get_ctx(int device, Ctx** out) {
     AM_HIP(fft_kernels_init());   // function attributes are per device
     Ctx* c = new Ctx();
     c->device = device;
+    c->hdr.flags = hipHostMallocMapped | hipHostMallocCoherent;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
     (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
@@ -425,6 +433,25 @@ static bool is_overshadowed(const am_peak& element, const am_peak* other, uint32
     return (e - b) < maxd && other->prominence > element.prominence;
 }
 
+// Makes `segs` the chunk list resident on the device.  Consecutive calls with
+// the same geometry (the common case: many haystacks of one length) reuse it.
+static int upload_segments(Ctx* c, const std::vector<Segment>& segs) {
+    const size_t bytes = sizeof(Segment) * segs.size();
+    if (c->segs.p && segs.size() == c->segs_resident.size() &&
+        memcmp(segs.data(), c->segs_resident.data(), bytes) == 0)
+        return AM_OK;
+    int rc;
+    c->segs_resident.clear();
+    if ((rc = c->segs.ensure(bytes))) return rc;
+    if ((rc = c->pinned.ensure(bytes))) return rc;
+    memcpy(c->pinned.p, segs.data(), bytes);
+    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, bytes, hipMemcpyHostToDevice, c->stream));
+    // the staging buffer is reused by the next upload: finish this one first (rare path)
+    AM_HIP(hipStreamSynchronize(c->stream));
+    c->segs_resident = segs;
+    return AM_OK;
+}
+
 // Launches find_peaks (audio_matcher.rs:221-230) for `nsegs` segments of a
 // resident score array; segment descriptors and result headers live at
 // [seg_off, seg_off + nsegs) of the context's segment / header buffers.
@@ -521,15 +548,12 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     if (max_segs > (size_t)1 << 18 || nsegs > (size_t)1 << 24)
         return fail(AM_ERR_INVALID_ARG, "chunk size too small for this haystack (more than 2^18 chunks)");
     int rc;
-    const size_t seg_bytes = sizeof(Segment) * nsegs, hdr_bytes = sizeof(SegHeader) * nsegs;
+    const size_t hdr_bytes = sizeof(SegHeader) * nsegs;
     if ((rc = c->scores.ensure(max_scores * sizeof(float)))) return rc;
-    if ((rc = c->segs.ensure(seg_bytes))) return rc;
     if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
-    if ((rc = c->pinned.ensure(seg_bytes + hdr_bytes + 64))) return rc;
-    memcpy(c->pinned.p, segs.data(), seg_bytes);
-    SegHeader* h_hdr = reinterpret_cast<SegHeader*>(static_cast<char*>(c->pinned.p) + ((seg_bytes + 63) & ~(size_t)63));
-    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, seg_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_segments(c, segs))) return rc;
+    SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
@@ -540,8 +564,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, seg_off[k], ns, p->min_prominence,
                               (long long)p->min_distance, &scan))) return rc;
     }
-    AM_HIP(hipMemcpyAsync(h_hdr, c->hdr.p, hdr_bytes, hipMemcpyDeviceToHost, c->stream));
-    AM_HIP(hipStreamSynchronize(c->stream));
+    AM_HIP(hipStreamSynchronize(c->stream));   // the headers are in host memory once the peak kernels have finished
     int worst = AM_OK;
     std::vector<am_peak> all;
     for (size_t k = 0; k < n_hay; ++k) {
@@ -569,8 +592,6 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                                       &full, src_kind))) return rc;
             if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, s0, s1 - s0, p->min_prominence,
                                   (long long)p->min_distance, &full))) return rc;
-            AM_HIP(hipMemcpyAsync(h_hdr + s0, (SegHeader*)c->hdr.p + s0, sizeof(SegHeader) * (s1 - s0),
-                                  hipMemcpyDeviceToHost, c->stream));
             AM_HIP(hipStreamSynchronize(c->stream));
             for (int i = s0; i < s1; ++i) {
                 if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
@@ -631,14 +652,11 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
     if ((rc = c->work2.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
     if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
-    const size_t seg_bytes = sizeof(Segment) * nsegs, hdr_bytes = sizeof(SegHeader) * nsegs * nn;
-    if ((rc = c->segs.ensure(seg_bytes))) return rc;
+    const size_t hdr_bytes = sizeof(SegHeader) * nsegs * nn;
     if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * (size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
-    if ((rc = c->pinned.ensure(seg_bytes + hdr_bytes + 64))) return rc;
-    memcpy(c->pinned.p, segs.data(), seg_bytes);
-    SegHeader* h_hdr = reinterpret_cast<SegHeader*>(static_cast<char*>(c->pinned.p) + ((seg_bytes + 63) & ~(size_t)63));
-    AM_HIP(hipMemcpyAsync(c->segs.p, c->pinned.p, seg_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_segments(c, segs))) return rc;
+    SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     const bool fused = plan_is_r16(pl->dev) && (hop % kTile) == 0;
     if (fused) {
         if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
@@ -672,7 +690,6 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
                               (long long)p->min_distance, &scan, (int)(k * nsegs)))) return rc;
     }
-    AM_HIP(hipMemcpyAsync(h_hdr, c->hdr.p, hdr_bytes, hipMemcpyDeviceToHost, c->stream));
     AM_HIP(hipStreamSynchronize(c->stream));
     int worst = AM_OK;
     std::vector<am_peak> all;
@@ -708,14 +725,12 @@ static int find_peaks_host_array(Ctx* c, const float* d_scores, long long n, flo
                                  std::vector<am_peak>& all) {
     int rc;
     Segment sg; sg.a = 0; sg.b = n;
-    if ((rc = c->segs.ensure(sizeof(Segment)))) return rc;
     if ((rc = c->hdr.ensure(sizeof(SegHeader)))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
-    AM_HIP(hipMemcpy(c->segs.p, &sg, sizeof(sg), hipMemcpyHostToDevice));
+    if ((rc = upload_segments(c, std::vector<Segment>(1, sg)))) return rc;
     if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr))) return rc;
     AM_HIP(hipStreamSynchronize(c->stream));
-    SegHeader hd;
-    AM_HIP(hipMemcpy(&hd, c->hdr.p, sizeof(hd), hipMemcpyDeviceToHost));
+    const SegHeader hd = *static_cast<const SegHeader*>(c->hdr.p);
     if (hd.overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
     all.resize(hd.n);
     if (hd.n > 0) AM_HIP(hipMemcpy(all.data(), c->peaks.p, sizeof(am_peak) * hd.n, hipMemcpyDeviceToHost));
@@ -1094,10 +1109,12 @@ int am_shutdown(void) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-        for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs, &c->hdr,
+        for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
                           &c->peaks, &c->io_in, &c->io_out, &c->sum})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
+        if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }
+        c->segs_resident.clear();
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
         c->plans.clear();
         for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

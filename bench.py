@@ -97,12 +97,15 @@ def pmc_traffic(kernel: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-steps", type=int, default=100,
+                    help="untimed steps run during setup, before the W warmup steps, so that the GPU has left its "
+                         "idle power state (the first ~50 ms of load run at lower clocks)")
     ap.add_argument("--haystacks-per-rank", type=int, default=2,
                     help="distinct resident 1 h haystacks each rank cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU sample (0 = one per thread)")
+    ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU sample (0 = three per thread, at most the whole hour)")
     ap.add_argument("--log-n", type=int, default=0)
     ap.add_argument("--pairs-per-group", type=int, default=0)
     ap.add_argument("--k2-variant", type=int, default=-1)
@@ -160,6 +163,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    for i in range(args.ramp_steps):
+        step(i)
     for i in range(args.warmup):
         k, peaks = step(i)
         assert [p.start for p in peaks] == plant_offsets(k), (k, peaks)
@@ -219,7 +224,9 @@ def main():
     # covers all pairs of one haystack
     per_step_bytes = {
         "k1_cols_fwd": npairs * n_fft * (8 + 8),          # two f32 blocks in, complex out
-        "k2_rows": npairs * n_fft * (8 + 8 + 8),          # complex in, needle spectrum in, complex out
+        # complex in, complex out; the needle spectrum (8 B per point of ONE transform) is
+        # shared by all pairs and has to come from HBM once per launch, not once per pair
+        "k2_rows": npairs * n_fft * (8 + 8) + n_fft * 8,
         "k3_cols_inv": npairs * n_fft * 8 + (out_count // 32) * 8,  # complex in, (min,max) per 32 scores out
     }
     dom = "k2_rows"   # the dominant kernel by time (checked below against the untimed breakdown)
@@ -230,6 +237,10 @@ def main():
     kernel_ms_total = sum(v[0] for v in kern.values())
     # whole-pipeline figure from the wall clock of the timed region (local rank)
     pipe_gbs = (SURVEY_BYTES_PER_SAMPLE * float(h) * args.steps) / local_dt / 1e9
+    # what this design has to move per step (K1 + K2 + K3 above), and the same from the PMC counters
+    design_bytes = float(sum(per_step_bytes.values()))
+    pmc_bytes = [pmc_traffic(k_) for k_ in ("k1_cols_fwd", "k2_rows", "k3_cols_inv", "tile_stats", "peaks")]
+    pmc_total = float(sum(pmc_bytes)) if all(b is not None for b in pmc_bytes) else None
     out = {
         "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -238,6 +249,7 @@ def main():
         "config": {"workload": "1 x 10 s mono 44.1 kHz f32 needle vs 1 x 1 h haystack per rank per step, "
                                "resident in HBM (BASELINE configs[1]); 6 planted hits per haystack",
                    "needle_samples": s, "haystack_samples": h, "fft_log2": log_n, "hop": hop,
+                   "ramp_steps": args.ramp_steps,
                    "sharding": f"{world} rank(s), independent haystacks, no collective"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
@@ -245,7 +257,12 @@ def main():
                      "launches": dom_launches},
         "roofline_pipeline": {"bound": "hbm", "achieved": pipe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": pipe_gbs / HBM_PEAK_GBS,
-                              "bytes_per_sample": SURVEY_BYTES_PER_SAMPLE, "basis": "wall clock of the timed region",
+                              "bytes_per_sample": SURVEY_BYTES_PER_SAMPLE,
+                              "basis": "SURVEY.md 8(d) model bytes (28 N per block at N = 2^22) over the wall clock of the timed region",
+                              "design_bytes_per_step": design_bytes,
+                              "design_frac": design_bytes * args.steps / local_dt / 1e9 / HBM_PEAK_GBS,
+                              "pmc_bytes_per_step": pmc_total,
+                              "pmc_frac": (pmc_total * args.steps / local_dt / 1e9 / HBM_PEAK_GBS) if pmc_total else None,
                               "dominant_by_time": max(KN, key=lambda n_: kern[n_][0]),
                               "kernel_ms_per_step": {n_: v[0] / args.steps for n_, v in kern.items()}},
     }
@@ -264,7 +281,7 @@ def main():
         del host
     if world == 1 and not args.no_cpu_baseline:
         threads = min(os.cpu_count() or 1, 16)
-        chunks = args.cpu_chunks or threads
+        chunks = args.cpu_chunks or min(3 * threads, HAY_S // CHUNK_S)
         out["cpu_baseline"] = cpu_baseline(chunks, threads)
     print(json.dumps(out))
     if dist is not None:
