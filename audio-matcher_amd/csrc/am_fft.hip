@@ -652,33 +652,54 @@ k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* _
     for (int a = 0; a < 16; ++a) buf_store2(rdst, voff, a * 4096, x[brev<16>(a)]);
 }
 
-// Reduction across the 16 lanes of a group of 16 per-lane values v[0..15]
-// (lane cp ends up with the reduction of v[cp]): log-step exchange in which
-// every step halves the rows a lane still carries.
-template <bool MAX>
-__device__ __forceinline__ float treduce16(const float (&v)[16], int cp) {
-    float w8[8], w4[4], w2[2];
+// v_min3 / v_max3 without the input canonicalisation the compiler puts in front of
+// fminf / fmaxf on values it cannot prove canonical (anything that came out of LDS)
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Score-scan exchange of K3: the workgroup's 256 x 32 scores of one block go
+// through LDS once so that thread t ends up with the whole 32-score run of row t
+// (16-byte chunk c of row r sits at chunk position c ^ (r & 7): both the 8-byte
+// writes of the column owners and the 16-byte reads of the row owners are
+// conflict-free).  (min, max) of a run then cost 16 + 16 three-input operations.
+__device__ __forceinline__ void scan_put(float2* lds2, unsigned wbase, const float (&c0)[16], const float (&c1)[16]) {
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const float send = (cp & 8) ? v[a] : v[a + 8], keep = (cp & 8) ? v[a + 8] : v[a];
-        const float r = lane_xor8(send);
-        w8[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
-    }
+    for (int a = 0; a < 16; ++a) lds2[a * 256 + wbase] = make_float2(c0[a], c1[a]);
+}
+// whole = every score of the run is valid; otherwise scores at run offsets >= nvalid are ignored
+__device__ __forceinline__ void scan_row_minmax(const float4* lds4, int t, bool whole, int nvalid, float& mn, float& mx) {
+    const unsigned k = (unsigned)t & 7u;
+    float4 v[8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const float send = (cp & 4) ? w8[a] : w8[a + 4], keep = (cp & 4) ? w8[a + 4] : w8[a];
-        const float r = lane_xor4(send);
-        w4[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
-    }
+    for (int i = 0; i < 8; ++i) v[i] = lds4[t * 8 + (int)((unsigned)i ^ k)];
+    if (!whole) {
+        mn = FLT_MAX; mx = -FLT_MAX;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const float send = (cp & 2) ? w4[a] : w4[a + 2], keep = (cp & 2) ? w4[a + 2] : w4[a];
-        const float r = lane_xor2(send);
-        w2[a] = MAX ? fmaxf(keep, r) : fminf(keep, r);
+        for (int i = 0; i < 8; ++i) {
+            const int c0 = (int)(((unsigned)i ^ k) << 2);   // first run offset held by this chunk
+            const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < nvalid) { mn = fminf(mn, e[j]); mx = fmaxf(mx, e[j]); }
+        }
+        return;
     }
-    const float send = (cp & 1) ? w2[0] : w2[1], keep = (cp & 1) ? w2[1] : w2[0];
-    const float r = lane_xor1(send);
-    return MAX ? fmaxf(keep, r) : fminf(keep, r);
+    mn = min3_raw(v[0].x, v[0].y, v[0].z); mx = max3_raw(v[0].x, v[0].y, v[0].z);
+    mn = min3_raw(mn, v[0].w, v[1].x);     mx = max3_raw(mx, v[0].w, v[1].x);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        if (i > 1) { mn = min3_raw(mn, v[i - 1].w, v[i].x); mx = max3_raw(mx, v[i - 1].w, v[i].x); }
+        mn = min3_raw(mn, v[i].y, v[i].z); mx = max3_raw(mx, v[i].y, v[i].z);
+    }
+    mn = fminf(mn, v[7].w); mx = fmaxf(mx, v[7].w);
 }
 
 // Does the 32-score run [lo, lo+32) hold the first (i*c) or the last
@@ -762,41 +783,30 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     bool wantA = true, wantB = true;
     if (scan.stats32 != nullptr) {
         // ---- fused score scan: (min,max) per 32 consecutive scores ------------
-        float mnA[16], mxA[16], mnB[16], mxB[16];
-        float tmaxA = -FLT_MAX, tmaxB = -FLT_MAX;
-        const int limAi = (int)limA, limBi = (int)(limB > 0 ? limB : 0);   // <= hop < 2^31
-        if (((limAi | limBi) & 31) == 0) {
-            // every 32-score run is wholly valid or wholly invalid (always, except in
-            // the block that holds the end of the score array)
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const int run = (a * 16 + hi) * out_stride + n2_0;
-                mnA[a] = fminf(sa0[a], sa1[a]); mxA[a] = fmaxf(sa0[a], sa1[a]);
-                mnB[a] = fminf(sb0[a], sb1[a]); mxB[a] = fmaxf(sb0[a], sb1[a]);
-                tmaxA = run < limAi ? fmaxf(tmaxA, mxA[a]) : tmaxA;
-                tmaxB = run < limBi ? fmaxf(tmaxB, mxB[a]) : tmaxB;
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                const int n = (a * 16 + hi) * out_stride + (int)col;
-                const bool a0v = n < limAi, a1v = n + 1 < limAi, b0v = n < limBi, b1v = n + 1 < limBi;
-                mnA[a] = fminf(a0v ? sa0[a] : FLT_MAX, a1v ? sa1[a] : FLT_MAX);
-                mxA[a] = fmaxf(a0v ? sa0[a] : -FLT_MAX, a1v ? sa1[a] : -FLT_MAX);
-                mnB[a] = fminf(b0v ? sb0[a] : FLT_MAX, b1v ? sb1[a] : FLT_MAX);
-                mxB[a] = fmaxf(b0v ? sb0[a] : -FLT_MAX, b1v ? sb1[a] : -FLT_MAX);
-                tmaxA = fmaxf(tmaxA, mxA[a]);
-                tmaxB = fmaxf(tmaxB, mxB[a]);
-            }
-        }
+        // thread t owns the run of row n1 = t (scores t*out_stride + n2_0 .. +31 of both blocks)
+        const long long rowrun = (long long)t * out_stride + n2_0;
+        // Every run is wholly valid or wholly invalid, except in the block that holds
+        // the end of the score array.
+        const long long leftA = limA - rowrun, leftB = limB - rowrun;
+        const bool wholeA = leftA >= 32 || leftA <= 0, wholeB = leftB >= 32 || leftB <= 0;
+        const unsigned wbase = (unsigned)hi * 16u + ((((unsigned)cp >> 1) ^ ((unsigned)hi & 7u)) << 1) + ((unsigned)cp & 1u);
+        const float4* lds4 = reinterpret_cast<const float4*>(lds2);
+        float rmnA, rmxA, rmnB, rmxB;
+        __syncthreads();   // the column exchange above is finished with the tile
+        scan_put(lds2, wbase, sa0, sa1);
+        __syncthreads();
+        scan_row_minmax(lds4, t, wholeA, (int)(leftA < 32 ? leftA : 32), rmnA, rmxA);
+        __syncthreads();
+        scan_put(lds2, wbase, sb0, sb1);
+        __syncthreads();
+        scan_row_minmax(lds4, t, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
         // raw scores leave the chip only for tiles that can matter to the peak
         // pick: some score >= theta, or a run that straddles a chunk edge
-        const long long rowrun = (long long)t * out_stride + n2_0;   // thread t checks row n1 = t
-        const bool edgeA = rowrun < limA && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
-        const bool edgeB = rowrun < limB && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+        const bool edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+        const bool edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         // one block-wide vote for both blocks: per-wave ballots into two LDS words
         // (zeroed before the exchange barriers above)
-        const bool pa = (tmaxA >= scan.theta) || edgeA, pb = (tmaxB >= scan.theta) || edgeB;
+        const bool pa = (leftA > 0 && rmxA >= scan.theta) || edgeA, pb = (leftB > 0 && rmxB >= scan.theta) || edgeB;
         if (__ballot(pa) && (t & 63) == 0) vote[0] = 1;
         if (__ballot(pb) && (t & 63) == 0) vote[1] = 1;
         __syncthreads();
@@ -807,12 +817,8 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
             scan.wflags[blkA * (out_stride >> kColsLog) + tile] = wantA ? 1 : 0;
             if (blkB < job.nblocks) scan.wflags[blkB * (out_stride >> kColsLog) + tile] = wantB ? 1 : 0;
         }
-        const float rmnA = treduce16<false>(mnA, cp), rmxA = treduce16<true>(mxA, cp);
-        const float rmnB = treduce16<false>(mnB, cp), rmxB = treduce16<true>(mxB, cp);
-        // lane cp now owns the summary of row n1 = cp*16 + hi
-        const long long run = (long long)(cp * 16 + hi) * out_stride + n2_0;
-        if (run < limA) scan.stats32[(outA + run) >> 5] = make_float2(rmnA, rmxA);
-        if (run < limB) scan.stats32[(outB + run) >> 5] = make_float2(rmnB, rmxB);
+        if (leftA > 0) scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
+        if (leftB > 0) scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
     }
     if (wantA) {
 #pragma unroll

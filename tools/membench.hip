@@ -75,9 +75,10 @@ __global__ void __launch_bounds__(256) stream_copy(const float4* s, float4* d, s
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
 }
 
-template<typename F> float timeit(F f, int reps = 10) {
+template<typename F> float timeit(F f, int reps = 100) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    f(); hipDeviceSynchronize();
+    for (int i = 0; i < 100; ++i) f();   // leave the idle power state (the first ~50 ms run at lower clocks)
+    hipDeviceSynchronize();
     hipEventRecord(a); for (int i = 0; i < reps; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
 }

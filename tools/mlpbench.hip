@@ -21,9 +21,10 @@ int main() {
     hipFuncSetAttribute((const void*)rowk, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int iters : {0, 10, 20, 40}) for (int lds : {65536, 49152, 32768}) {
-        rowk<<<nwg, 256, lds>>>(A, iters); hipDeviceSynchronize();
-        hipEventRecord(e0); for (int r = 0; r < 5; ++r) rowk<<<nwg, 256, lds>>>(A, iters); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+        for (int r = 0; r < 100; ++r) rowk<<<nwg, 256, lds>>>(A, iters);   // clock ramp
+        hipDeviceSynchronize();
+        hipEventRecord(e0); for (int r = 0; r < 50; ++r) rowk<<<nwg, 256, lds>>>(A, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 50;
         printf("fma iters=%2d (%4d VALU/thread) lds=%5d (%d WG/CU): %.3f ms  %.2f TB/s\n", iters, iters * 64, lds, 163840 / lds, ms, 2 * n4 * 16 / 1e9 / ms);
     }
     return 0;
