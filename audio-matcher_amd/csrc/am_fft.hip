@@ -723,6 +723,11 @@ __device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, lo
     return mod_recip(hi2, c, inv_c) <= 31;
 }
 
+// small block-shared state of K3's fused scan
+struct K3Shared {
+    int vote[2];
+};
+
 // K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
@@ -731,13 +736,34 @@ __device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, lo
 // b' order, columns col, col+1) are in registers: conjugate pipeline twiddle,
 // inverse 256-point column FFT, scaling, fused score scan, conditional raw-score
 // store.  Output index of row n1, column c is n1 * out_stride + c.
-__device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2, int* vote,
+__device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2, K3Shared* sh,
                                         int n2_0, int out_stride, int t, long long blkA, long long blkB,
                                         float out_scale, float2 (&x0)[16], float2 (&x1)[16]) {
     const int hi = t >> 4, cp = t & 15;
     const long long N = 1ll << pl.logN;
     const long long col = n2_0 + 2 * cp;
+    int* vote = sh->vote;
     if (t < 2) vote[t] = 0;
+    // Chunk edges (scores i*c and i*c + d, audio_matcher.rs:104, 119).  With chunks longer
+    // than a block (the usual case) each block holds at most one edge of either kind;
+    // their positions depend on the block only and are worked out here, while the
+    // tile's loads are still in flight.
+    const long long outA = blkA * job.hop, outB = blkB * job.hop;
+    const bool one_edge = scan.stats32 != nullptr && scan.seg_c >= (long long)job.hop + 32;
+    long long ecA = 0, edA = 0, ecB = 0, edB = 0;
+    if (one_edge) {
+        const long long c = scan.seg_c, d = scan.seg_d;
+        const long long m = mod_recip(outA, c, scan.inv_c);
+        ecA = m == 0 ? outA : outA + (c - m);            // smallest i*c >= outA
+        edA = d;                                         // smallest i*c + d >= outA, i >= 0
+        if (outA > d) {
+            const long long m2 = mod_recip(outA - d, c, scan.inv_c);
+            edA = m2 == 0 ? outA : outA + (c - m2);
+        }
+        // block B starts hop < c later: its first edge is the same one or the next
+        ecB = ecA >= outB ? ecA : ecA + c;
+        edB = edA >= outB ? edA : edA + c;
+    }
     const unsigned maskN = (unsigned)(N - 1);
     const float2 w256 = pl.tw1[hi];
     {
@@ -768,7 +794,6 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     twiddle_nat<16, true>(x1, w256);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
-    const long long outA = blkA * job.hop, outB = blkB * job.hop;
     const bool dst8 = ((reinterpret_cast<uintptr_t>(job.dst) & 7) == 0) && ((job.hop & 1) == 0);
     long long limA = job.out_count - outA; if (limA > job.hop) limA = job.hop;
     long long limB = blkB < job.nblocks ? job.out_count - outB : 0; if (limB > job.hop) limB = job.hop;
@@ -802,8 +827,15 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
         scan_row_minmax(lds4, t, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
         // raw scores leave the chip only for tiles that can matter to the peak
         // pick: some score >= theta, or a run that straddles a chunk edge
-        const bool edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
-        const bool edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+        bool edgeA, edgeB;
+        if (one_edge) {
+            const unsigned long long loA = (unsigned long long)(outA + rowrun), loB = (unsigned long long)(outB + rowrun);
+            edgeA = leftA > 0 && ((unsigned long long)ecA - loA <= 31ull || (unsigned long long)edA - loA <= 31ull);
+            edgeB = leftB > 0 && ((unsigned long long)ecB - loB <= 31ull || (unsigned long long)edB - loB <= 31ull);
+        } else {
+            edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+            edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+        }
         // one block-wide vote for both blocks: per-wave ballots into two LDS words
         // (zeroed before the exchange barriers above)
         const bool pa = (leftA > 0 && rmxA >= scan.theta) || edgeA, pb = (leftB > 0 && rmxB >= scan.theta) || edgeB;
@@ -850,7 +882,7 @@ template <bool HALF>
 __global__ void __launch_bounds__(256, 3)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
-    __shared__ int vote[2];
+    __shared__ K3Shared sh;
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     // XCD-aware placement (speed only): the 16 adjacent column tiles that share
@@ -879,7 +911,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
             x1[bp] = make_float2(v.z, v.w);
         }
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), vote, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
@@ -892,7 +924,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 __global__ void __launch_bounds__(256, 3)
 k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
-    __shared__ int vote[2];
+    __shared__ K3Shared sh;
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
@@ -918,7 +950,7 @@ k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
         x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), vote, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
