@@ -52,6 +52,7 @@ static long long g_opt_pairs_per_group = 64;
 static long long g_opt_profile_mask = -1;    // bit i = bracket kernel class i with events while profiling is on
 static long long g_opt_lanes = 1;           // 2 = overlap the kernels of alternate pair groups on two streams
 static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
+static long long g_opt_needle_group = 4;    // needles sharing one forward row transform in am_match_multi_device
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
@@ -180,6 +181,19 @@ static void prof_harvest(Ctx* c) {
     c->pending.clear();
 }
 
+// ---- copies ------------------------------------------------------------------
+// Every copy of the library runs on the context's stream and is waited for there.
+// That stream is non-blocking, i.e. not ordered with the null stream a plain
+// hipMemcpy uses; a device-to-device hipMemcpy returns before the copy has run and
+// a copy from pageable host memory may return once the data is staged, so kernels
+// queued on the context's stream right afterwards could otherwise read data that has
+// not arrived yet.
+static hipError_t copy_on_stream(Ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(c->stream);
+}
+
 // ---- plans --------------------------------------------------------------------
 static void fill_twiddles(std::vector<float2>& v, size_t off, size_t count, double denom, double mult) {
     for (size_t k = 0; k < count; ++k) {
@@ -209,7 +223,7 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     fill_twiddles(host, n1h + n2h, nlo, (double)((size_t)1 << logN), 1.0);
     fill_twiddles(host, n1h + n2h + nlo, nhi, (double)((size_t)1 << logN), (double)nlo);
     AM_HIP(hipMalloc((void**)&p.tables, host.size() * sizeof(float2)));
-    AM_HIP(hipMemcpy(p.tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, p.tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
     p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo; p.dev.wide = wide;
     p.dev.tw1 = p.tables;
     p.dev.tw2 = p.tables + n1h;
@@ -599,7 +613,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                 if (cnt <= 0) continue;
                 const size_t old = all.size();
                 all.resize(old + cnt);
-                AM_HIP(hipMemcpy(all.data() + old, (am_peak*)c->peaks.p + (size_t)(i - s0) * AM_MAX_PEAKS_PER_CHUNK,
+                AM_HIP(copy_on_stream(c, all.data() + old, (am_peak*)c->peaks.p + (size_t)(i - s0) * AM_MAX_PEAKS_PER_CHUNK,
                                  sizeof(am_peak) * cnt, hipMemcpyDeviceToHost));
             }
         }
@@ -650,7 +664,12 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     for (size_t k = 0; k < nn; ++k)
         if ((rc = needle_spectrum(needles[k], pl, &hcs[k]))) return rc;   // may use c->work: before it is filled
     if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
-    if ((rc = c->work2.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
+    const bool half = g_opt_half && plan_is_r16(pl->dev) && !pl->dev.wide && g_k2_variant == 0;
+    // needles are taken in groups that share the forward row transforms of K2
+    const size_t group = (!half && plan_k2_has_group(pl->dev))
+        ? (size_t)std::min<long long>(std::max<long long>(1, g_opt_needle_group), kMaxNeedleGroup) : 1;
+    const size_t matrix = (size_t)npairs * (size_t)N;   // points of one needle's work matrix
+    if ((rc = c->work2.ensure(std::min(group, nn) * matrix * sizeof(float2)))) return rc;
     if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
     const size_t hdr_bytes = sizeof(SegHeader) * nsegs * nn;
     if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
@@ -666,10 +685,18 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     job.src = d_hay; job.src_len = (long long)len; job.lead = 0; job.src_kind = src_kind;
     job.dst = (float*)c->scores.p; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
     job.first_pair = 0;
-    const bool half = g_opt_half && plan_is_r16(pl->dev) && !pl->dev.wide && g_k2_variant == 0;
     { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)npairs, (float2*)c->work.p, pl->dev, half)); }
     for (size_t k = 0; k < nn; ++k) {
         am_needle* h = needles[k];
+        const size_t in_group = k % group;
+        const float2* inv_rows = (const float2*)c->work2.p + in_group * matrix;   // this needle's inverse rows
+        if (group > 1 && in_group == 0) {
+            K2Group grp{};
+            grp.n = (int)std::min(group, nn - k);
+            for (int j = 0; j < grp.n; ++j) { grp.hc[j] = hcs[k + j]; grp.dst[j] = (float2*)c->work2.p + (size_t)j * matrix; }
+            ProfScope ps(c, KN_K2);
+            AM_HIP(launch_k2_group(c->stream, (int)npairs, (const float2*)c->work.p, grp, pl->dev));
+        }
         ScanRequest scan{};
         scan.theta = (h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
         scan.seg_c = (long long)p->chunk;
@@ -684,8 +711,8 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         }
         const float factor = scale_factor(h, p->scale, 1);
         const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, half, hscale)); }
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, (const float2*)c->work2.p, pl->dev,
+        if (group == 1) { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, half, hscale)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, inv_rows, pl->dev,
                                                   half ? factor / hscale : factor, cfg, half)); }
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
                               (long long)p->min_distance, &scan, (int)(k * nsegs)))) return rc;
@@ -733,7 +760,7 @@ static int find_peaks_host_array(Ctx* c, const float* d_scores, long long n, flo
     const SegHeader hd = *static_cast<const SegHeader*>(c->hdr.p);
     if (hd.overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
     all.resize(hd.n);
-    if (hd.n > 0) AM_HIP(hipMemcpy(all.data(), c->peaks.p, sizeof(am_peak) * hd.n, hipMemcpyDeviceToHost));
+    if (hd.n > 0) AM_HIP(copy_on_stream(c, all.data(), c->peaks.p, sizeof(am_peak) * hd.n, hipMemcpyDeviceToHost));
     return AM_OK;
 }
 
@@ -752,7 +779,7 @@ static int create_needle_common(Ctx* c, float* d_needle, size_t n, am_needle** o
     hipError_t e = launch_sumsq(c->stream, d_needle, (long long)n, (double*)c->sum.p);
     std::vector<double> part((size_t)parts, 0.0);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(part.data(), c->sum.p, sizeof(double) * (size_t)parts, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = copy_on_stream(c, part.data(), c->sum.p, sizeof(double) * (size_t)parts, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { (void)hipFree(d_needle); delete h; return hip_fail(e, "needle energy"); }
     double ss = 0.0;
     for (double v : part) ss += v;
@@ -788,8 +815,8 @@ int am_needle_create(int device, const float* needle, size_t n, am_needle** out)
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     float* d = nullptr;
     AM_HIP(hipMalloc((void**)&d, n * sizeof(float)));
-    hipError_t e = hipMemcpy(d, needle, n * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(needle)"); }
+    hipError_t e = copy_on_stream(c, d, needle, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "copy_on_stream(c, needle)"); }
     return create_needle_common(c, d, n, out);
 }
 
@@ -801,12 +828,8 @@ int am_needle_create_device(int device, const float* d_needle, size_t n, am_need
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     float* d = nullptr;
     AM_HIP(hipMalloc((void**)&d, n * sizeof(float)));
-    // On the context's stream: a device-to-device hipMemcpy returns before the copy
-    // has run and the null stream does not order with this non-blocking stream, so
-    // the energy reduction below could otherwise read a partly copied needle.
-    hipError_t e = hipMemcpyAsync(d, d_needle, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "hipMemcpy(needle d2d)"); }
+    hipError_t e = copy_on_stream(c, d, d_needle, n * sizeof(float), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "copy_on_stream(c, needle d2d)"); }
     return create_needle_common(c, d, n, out);
 }
 
@@ -862,13 +885,13 @@ static int correlate_impl(const am_needle* hc, const float* within, size_t w, in
     if (!device_io) {
         if ((rc = c->io_in.ensure(w * sizeof(float)))) return rc;
         if ((rc = c->io_out.ensure(len * sizeof(float)))) return rc;
-        AM_HIP(hipMemcpy(c->io_in.p, within, w * sizeof(float), hipMemcpyHostToDevice));
+        AM_HIP(copy_on_stream(c, c->io_in.p, within, w * sizeof(float), hipMemcpyHostToDevice));
         d_in = (const float*)c->io_in.p;
         d_out = (float*)c->io_out.p;
     }
     if ((rc = run_correlation(h, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
     AM_HIP(hipStreamSynchronize(c->stream));
-    if (!device_io) AM_HIP(hipMemcpy(out, d_out, len * sizeof(float), hipMemcpyDeviceToHost));
+    if (!device_io) AM_HIP(copy_on_stream(c, out, d_out, len * sizeof(float), hipMemcpyDeviceToHost));
     return AM_OK;
 }
 
@@ -904,7 +927,7 @@ int am_match(const am_needle* hc, const float* haystack, size_t len,
     Ctx* c = h->ctx;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(len * sizeof(float)))) return rc;
-    AM_HIP(hipMemcpy(c->io_in.p, haystack, len * sizeof(float), hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, c->io_in.p, haystack, len * sizeof(float), hipMemcpyHostToDevice));
     const void* d_in = c->io_in.p;
     return match_many(h, &d_in, &len, 1, p, out, cap, n_out);
 }
@@ -958,7 +981,7 @@ int am_match_pcm16(const am_needle* hc, const int16_t* interleaved, size_t frame
     Ctx* c = h->ctx;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(frames * 2 * sizeof(int16_t)))) return rc;
-    AM_HIP(hipMemcpy(c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
     const void* d_in = c->io_in.p;
     return match_many(h, &d_in, &frames, 1, p, out, cap, n_out, 1);
 }
@@ -982,7 +1005,7 @@ int am_needle_create_pcm16(int device, const int16_t* interleaved, size_t frames
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(frames * 2 * sizeof(int16_t)))) return rc;
-    AM_HIP(hipMemcpy(c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
     float* d = nullptr;
     AM_HIP(hipMalloc((void**)&d, frames * sizeof(float)));
     hipError_t e = launch_pcm_downmix(c->stream, (const int16_t*)c->io_in.p, (long long)frames, d);
@@ -1001,7 +1024,7 @@ int am_find_peaks(int device, const float* scores, size_t n, float min_prominenc
     if (n == 0) return AM_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(n * sizeof(float)))) return rc;
-    AM_HIP(hipMemcpy(c->io_in.p, scores, n * sizeof(float), hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, c->io_in.p, scores, n * sizeof(float), hipMemcpyHostToDevice));
     std::vector<am_peak> all;
     if ((rc = find_peaks_host_array(c, (const float*)c->io_in.p, (long long)n, min_prominence,
                                     (long long)min_distance, all))) return rc;
@@ -1032,10 +1055,10 @@ int am_pcm_s16_stereo_to_mono(int device, const int16_t* interleaved, size_t fra
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if ((rc = c->io_in.ensure(frames * 2 * sizeof(int16_t)))) return rc;
     if ((rc = c->io_out.ensure(frames * sizeof(float)))) return rc;
-    AM_HIP(hipMemcpy(c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, c->io_in.p, interleaved, frames * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
     AM_HIP(launch_pcm_downmix(c->stream, (const int16_t*)c->io_in.p, (long long)frames, (float*)c->io_out.p));
     AM_HIP(hipStreamSynchronize(c->stream));
-    AM_HIP(hipMemcpy(out, c->io_out.p, frames * sizeof(float), hipMemcpyDeviceToHost));
+    AM_HIP(copy_on_stream(c, out, c->io_out.p, frames * sizeof(float), hipMemcpyDeviceToHost));
     return AM_OK;
 }
 
@@ -1058,14 +1081,14 @@ int am_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes) {
     Ctx* c = nullptr;
     int rc = get_ctx(device, &c);
     if (rc) return rc;
-    AM_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    AM_HIP(copy_on_stream(c, d_dst, src, bytes, hipMemcpyHostToDevice));
     return AM_OK;
 }
 int am_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes) {
     Ctx* c = nullptr;
     int rc = get_ctx(device, &c);
     if (rc) return rc;
-    AM_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    AM_HIP(copy_on_stream(c, dst, d_src, bytes, hipMemcpyDeviceToHost));
     return AM_OK;
 }
 int am_device_synchronize(int device) {
@@ -1172,6 +1195,10 @@ int am_set_option(const char* key, long long value) {
         g_opt_log_n = value; return AM_OK;
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "needle_group")) {
+        if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
+        g_opt_needle_group = value; return AM_OK;
+    }
     if (!strcmp(key, "profile_mask")) { g_opt_profile_mask = value; return AM_OK; }
     if (!strcmp(key, "lanes")) {
         if (value != 1 && value != 2) return fail(AM_ERR_INVALID_ARG, "lanes must be 1 or 2");
@@ -1193,6 +1220,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "pairs_per_group")) { *value = g_opt_pairs_per_group; return AM_OK; }
     if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
     if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
+    if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
     if (!strcmp(key, "lanes")) { *value = g_opt_lanes; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");

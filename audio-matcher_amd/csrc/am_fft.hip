@@ -368,40 +368,36 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 // K2: one 8192-point row: forward FFT (16 x 16 x 32), multiply by conj(H)/N,
-// inverse FFT.  SPECTRUM = true stores conj(FFT)/N of the needle instead
-// (fft_b, the conj of pairwise_mult_in_place and the 1/len of
-// audio_matcher.rs:430-442 folded into one table).
-template <bool SPECTRUM, bool HALF>
-__global__ void __launch_bounds__(256, 2)
-k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl,
-            unsigned npairs, float hscale) {
-    extern __shared__ float4 lds4[];
-    const int t = threadIdx.x;
-    const int hi = t >> 4, cp = t & 15;
-    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never
-    // correctness): give every XCD whole rows, so that the needle-spectrum row
-    // shared by all pairs is fetched into that XCD's L2 once.
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned row = (seq / npairs) * 8u + xcd, slot = seq % npairs;
-    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
-    // one point is 8 bytes (float2) or, with half storage, 4 bytes (__half2)
-    const __amdgpu_buffer_rsrc_t rrow = HALF ? make_rsrc(reinterpret_cast<unsigned*>(work) + row_off, kN2 * 4)
-                                             : make_rsrc(work + row_off, kN2 * 8);
-    const size_t hoff4 = (size_t)row * (kN2 / 2);
-    const unsigned voff = (unsigned)t * 16u;
-    // twiddle seeds of both pass boundaries, fetched beside the row so that their
-    // (L2) latency is not exposed in the middle of the transform
-    const float2 wj0 = pl.tw2[2 * t], wj1 = pl.tw2[2 * t + 1];
-    const float2 wc0 = pl.tw2[32 * cp], wc1 = pl.tw2[32 * cp + 16];
+// inverse FFT.  The three stages below are shared by the single-needle kernel
+// and the needle-group kernel.
+struct K2Lane {
+    int t, hi, cp;
+    unsigned voff;               // byte offset of the thread's first float4 in a row
+    float2 wj0, wj1, wc0, wc1;   // twiddle seeds of both pass boundaries
+};
+__device__ __forceinline__ K2Lane k2_lane(const PlanDev& pl) {
+    K2Lane k;
+    k.t = threadIdx.x; k.hi = k.t >> 4; k.cp = k.t & 15;
+    k.voff = (unsigned)k.t * 16u;
+    // fetched beside the row so that their (L2) latency is not exposed in the middle of the transform
+    k.wj0 = pl.tw2[2 * k.t]; k.wj1 = pl.tw2[2 * k.t + 1];
+    k.wc0 = pl.tw2[32 * k.cp]; k.wc1 = pl.tw2[32 * k.cp + 16];
+    return k;
+}
+
+// row load + forward passes 1 and 2; leaves the row in LDS in the layout pass 3 reads
+template <bool HALF>
+__device__ __forceinline__ void k2_forward12(const K2Lane& k, __amdgpu_buffer_rsrc_t rrow, float4* lds4) {
+    const int t = k.t, hi = k.hi, cp = k.cp;
     float2 x0[16], x1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
         if (HALF) {
-            const uint2 v = buf_load_u2(rrow, voff / 2, a * 2048);
+            const uint2 v = buf_load_u2(rrow, k.voff / 2, a * 2048);
             x0[a] = unpack_h2(v.x);
             x1[a] = unpack_h2(v.y);
         } else {
-            const float4 v = buf_load4(rrow, voff, a * 4096);
+            const float4 v = buf_load4(rrow, k.voff, a * 4096);
             x0[a] = make_float2(v.x, v.y);
             x1[a] = make_float2(v.z, v.w);
         }
@@ -409,8 +405,8 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1 ----
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, wj0);
-    twiddle_brev<16, false>(x1, wj1);
+    twiddle_brev<16, false>(x0, k.wj0);
+    twiddle_brev<16, false>(x1, k.wj1);
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap)   // L1[a'][j]
         lds4[ap * 256 + t] = make_float4(x0[brev<16>(ap)].x, x0[brev<16>(ap)].y,
@@ -425,53 +421,72 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, wc0);
-    twiddle_brev<16, false>(x1, wc1);
+    twiddle_brev<16, false>(x0, k.wc0);
+    twiddle_brev<16, false>(x1, k.wc1);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp)   // L2 row u = a'*16 + b', slot cp ^ b'
         lds4[(hi * 16 + bp) * 16 + (cp ^ bp)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
                                                             x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
-    // the needle-spectrum row (L2-resident) is requested here, where only the 32
-    // points of pass 3 are live, so that its latency hides behind that pass
-    float4 h[16];
-    if (!SPECTRUM) {
-        __builtin_amdgcn_sched_barrier(0);
-        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + hoff4, kN2 * 8);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, voff, i * 4096);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- pass 3 over c (32 contiguous): thread owns row u = t ----
-    float2 z[32];
+}
+
+// ---- pass 3 over c (32 contiguous): thread owns row u = t; z[r] = frequency brev(r) of that row ----
+__device__ __forceinline__ void k2_forward3(const K2Lane& k, const float4* lds4, float2 (&z)[32]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float4 v = lds4[t * 16 + (i ^ cp)];
+        const float4 v = lds4[k.t * 16 + (i ^ k.cp)];
         z[2 * i] = make_float2(v.x, v.y);
         z[2 * i + 1] = make_float2(v.z, v.w);
     }
     dif<32, false>(z);
-    if (SPECTRUM) {
-        const float invN = 1.0f / (float)(1u << pl.logN);
-        const __amdgpu_buffer_rsrc_t rho = make_rsrc(reinterpret_cast<float4*>(hc_out) + hoff4, kN2 * 8);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            buf_store4(rho, voff, i * 4096, make_float4(z[2 * i].x * invN, -z[2 * i].y * invN,
-                                                       z[2 * i + 1].x * invN, -z[2 * i + 1].y * invN));
-        return;
-    }
-    // ---- pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438) ----
-    float2 q[32];
+}
+
+// pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438)
+// q = z * h in the order the inverse wants (z[r] holds frequency brev(r); the inverse takes natural order)
+__device__ __forceinline__ void k2_multiply(const float2 (&z)[32], const float4 (&h)[16], float hscale, float2 (&q)[32]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         // hscale != 1 only with half storage: keeps the stored values well inside f16's range
-        const float2 m0 = cmul(z[2 * i], make_float2(h[i].x * hscale, h[i].y * hscale));
-        const float2 m1 = cmul(z[2 * i + 1], make_float2(h[i].z * hscale, h[i].w * hscale));
-        // z[r] holds frequency brev(r): hand the inverse its input in natural order
-        q[brev<32>(2 * i)] = m0;
-        q[brev<32>(2 * i + 1)] = m1;
+        q[brev<32>(2 * i)] = cmul(z[2 * i], make_float2(h[i].x * hscale, h[i].y * hscale));
+        q[brev<32>(2 * i + 1)] = cmul(z[2 * i + 1], make_float2(h[i].z * hscale, h[i].w * hscale));
     }
+}
+// The same with the spectrum row fetched a quarter at a time (needle-group kernel: z
+// stays live across needles, so z, q and a whole spectrum row do not fit the register
+// file together).  The fetch of a quarter is in flight while the previous one is used;
+// `first` is quarter 0, requested by the caller ahead of time.
+__device__ __forceinline__ void k2_fetch_quarter(__amdgpu_buffer_rsrc_t rh, unsigned voff, int part, float4 (&h)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = buf_load4(rh, voff, (part * 4 + i) * 4096);
+}
+__device__ __forceinline__ void k2_multiply_quarter(const float2 (&z)[32], const float4 (&h)[4], int part, float2 (&q)[32]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = part * 4 + i;
+        q[brev<32>(2 * e)] = cmul(z[2 * e], make_float2(h[i].x, h[i].y));
+        q[brev<32>(2 * e + 1)] = cmul(z[2 * e + 1], make_float2(h[i].z, h[i].w));
+    }
+}
+__device__ __forceinline__ void k2_multiply_fetch(const float2 (&z)[32], __amdgpu_buffer_rsrc_t rh, unsigned voff,
+                                                  const float4 (&first)[4], float2 (&q)[32]) {
+    float4 ha[4], hb[4];
+    k2_fetch_quarter(rh, voff, 1, ha);
+    __builtin_amdgcn_sched_barrier(0);
+    k2_multiply_quarter(z, first, 0, q);
+    k2_fetch_quarter(rh, voff, 2, hb);
+    __builtin_amdgcn_sched_barrier(0);
+    k2_multiply_quarter(z, ha, 1, q);
+    k2_fetch_quarter(rh, voff, 3, ha);
+    __builtin_amdgcn_sched_barrier(0);
+    k2_multiply_quarter(z, hb, 2, q);
+    k2_multiply_quarter(z, ha, 3, q);
+}
+
+// inverse passes 3, 2, 1 of the product q and the row store
+template <bool HALF>
+__device__ __forceinline__ void k2_inverse(const K2Lane& k, float2 (&q)[32], float4* lds4, __amdgpu_buffer_rsrc_t rdst) {
+    const int t = k.t, hi = k.hi, cp = k.cp;
     // ---- inverse pass 3 over c' ----
     dif<32, true>(q);   // time index c at q[brev(c)]
 #pragma unroll
@@ -480,14 +495,15 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
                                               q[brev<32>(2 * i + 1)].x, q[brev<32>(2 * i + 1)].y);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
     // ---- inverse pass 2 over b': conj twiddle first, then butterflies ----
+    float2 x0[16], x1[16];
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
         const float4 v = lds4[(hi * 16 + bp) * 16 + (cp ^ bp)];
         x0[bp] = make_float2(v.x, v.y);
         x1[bp] = make_float2(v.z, v.w);
     }
-    twiddle_nat<16, true>(x0, wc0);
-    twiddle_nat<16, true>(x1, wc1);
+    twiddle_nat<16, true>(x0, k.wc0);
+    twiddle_nat<16, true>(x1, k.wc1);
     dif<16, true>(x0);
     dif<16, true>(x1);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
@@ -503,24 +519,115 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
         x0[ap] = make_float2(v.x, v.y);
         x1[ap] = make_float2(v.z, v.w);
     }
-    twiddle_nat<16, true>(x0, wj0);
-    twiddle_nat<16, true>(x1, wj1);
+    twiddle_nat<16, true>(x0, k.wj0);
+    twiddle_nat<16, true>(x1, k.wj1);
     dif<16, true>(x0);
     dif<16, true>(x1);
-    // in place, or into a second work matrix (hc_out doubles as that destination
-    // when several needles share one forward pass, am_match_multi_device)
     if (HALF) {
-        const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(reinterpret_cast<unsigned*>(hc_out) + row_off, kN2 * 4) : rrow;
 #pragma unroll
         for (int a = 0; a < 16; ++a)
-            buf_store_u2(rdst, voff / 2, a * 2048, make_uint2(pack_h2(x0[brev<16>(a)]), pack_h2(x1[brev<16>(a)])));
+            buf_store_u2(rdst, k.voff / 2, a * 2048, make_uint2(pack_h2(x0[brev<16>(a)]), pack_h2(x1[brev<16>(a)])));
         return;
     }
-    const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(hc_out + row_off, kN2 * 8) : rrow;
 #pragma unroll
     for (int a = 0; a < 16; ++a)
-        buf_store4(rdst, voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
-                                                     x1[brev<16>(a)].x, x1[brev<16>(a)].y));
+        buf_store4(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+                                                       x1[brev<16>(a)].x, x1[brev<16>(a)].y));
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (speed only, never
+// correctness): give every XCD whole rows, so that the needle-spectrum row
+// shared by all pairs is fetched into that XCD's L2 once.
+__device__ __forceinline__ void k2_place(unsigned npairs, unsigned& row, unsigned& slot) {
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    row = (seq / npairs) * 8u + xcd;
+    slot = seq % npairs;
+}
+
+// SPECTRUM = true stores conj(FFT)/N of the needle instead (fft_b, the conj of
+// pairwise_mult_in_place and the 1/len of audio_matcher.rs:430-442 folded into
+// one table).
+template <bool SPECTRUM, bool HALF>
+__global__ void __launch_bounds__(256, 2)
+k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl,
+            unsigned npairs, float hscale) {
+    extern __shared__ float4 lds4[];
+    unsigned row, slot;
+    k2_place(npairs, row, slot);
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    // one point is 8 bytes (float2) or, with half storage, 4 bytes (__half2)
+    const __amdgpu_buffer_rsrc_t rrow = HALF ? make_rsrc(reinterpret_cast<unsigned*>(work) + row_off, kN2 * 4)
+                                             : make_rsrc(work + row_off, kN2 * 8);
+    const size_t hoff4 = (size_t)row * (kN2 / 2);
+    const K2Lane k = k2_lane(pl);
+    k2_forward12<HALF>(k, rrow, lds4);
+    // the needle-spectrum row (L2-resident) is requested here, where only the 32
+    // points of pass 3 are live, so that its latency hides behind that pass
+    float4 h[16];
+    if (!SPECTRUM) {
+        __builtin_amdgcn_sched_barrier(0);
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + hoff4, kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, k.voff, i * 4096);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float2 z[32];
+    k2_forward3(k, lds4, z);
+    if (SPECTRUM) {
+        const float invN = 1.0f / (float)(1u << pl.logN);
+        const __amdgpu_buffer_rsrc_t rho = make_rsrc(reinterpret_cast<float4*>(hc_out) + hoff4, kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            buf_store4(rho, k.voff, i * 4096, make_float4(z[2 * i].x * invN, -z[2 * i].y * invN,
+                                                         z[2 * i + 1].x * invN, -z[2 * i + 1].y * invN));
+        return;
+    }
+    // in place, or into a second work matrix (hc_out doubles as that destination)
+    const __amdgpu_buffer_rsrc_t rdst = !hc_out ? rrow
+        : HALF ? make_rsrc(reinterpret_cast<unsigned*>(hc_out) + row_off, kN2 * 4) : make_rsrc(hc_out + row_off, kN2 * 8);
+    float2 q[32];
+    k2_multiply(z, h, hscale, q);
+    k2_inverse<HALF>(k, q, lds4, rdst);
+}
+
+// K2 for a group of needles against one haystack (am_match_multi_device, BASELINE
+// config 4): the row is read and transformed ONCE; every needle of the group then
+// multiplies that spectrum with its own and runs its own inverse transform into its
+// own work matrix.  Per needle the row costs 8/n + 8 bytes of HBM traffic instead of
+// 16 and the forward half of the arithmetic is shared.
+__global__ void __launch_bounds__(256, 2)
+k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsigned npairs) {
+    extern __shared__ float4 lds4[];
+    unsigned row, slot;
+    k2_place(npairs, row, slot);
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
+    const size_t hoff4 = (size_t)row * (kN2 / 2);
+    const K2Lane k = k2_lane(pl);
+    k2_forward12<false>(k, rrow, lds4);
+    float2 z[32];
+    k2_forward3(k, lds4, z);
+    // the first quarter of a needle's spectrum row is requested one needle ahead, so
+    // that its latency hides behind the previous needle's inverse passes
+    float4 hq[4];
+    k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[0]) + hoff4, kN2 * 8), k.voff, 0, hq);
+#pragma unroll 1
+    for (int j = 0; j < grp.n; ++j) {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(grp.hc[j]) + hoff4, kN2 * 8);
+        // The twiddle powers of the inverse passes depend on the lane only; left alone
+        // the compiler computes them once before the loop and keeps ~120 values alive
+        // across it (in scratch).  Recomputing them per needle is far cheaper.
+        K2Lane kj = k;
+        asm volatile("" : "+v"(kj.wj0.x), "+v"(kj.wj0.y), "+v"(kj.wj1.x), "+v"(kj.wj1.y),
+                          "+v"(kj.wc0.x), "+v"(kj.wc0.y), "+v"(kj.wc1.x), "+v"(kj.wc1.y));
+        float2 q[32];
+        k2_multiply_fetch(z, rh, k.voff, hq, q);
+        const int jn = j + 1 < grp.n ? j + 1 : j;   // (the last needle refetches its own quarter: harmless)
+        k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[jn]) + hoff4, kN2 * 8), k.voff, 0, hq);
+        __builtin_amdgcn_sched_barrier(0);
+        k2_inverse<false>(kj, q, lds4, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
+        __syncthreads();   // the last pass read rows of every wave: finish before the next needle overwrites them
+    }
 }
 
 // Lane exchanges as DPP moves (VALU) rather than ds_bpermute (LDS pipe).
@@ -1182,6 +1289,7 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<false, true>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
+    AM_SET_LDS(k2_rows_r16_group, kR16Lds)
     AM_SET_LDS(k2_rows_p512<false>, kR16Lds)
     AM_SET_LDS(k2_rows_p512<true>, kR16Lds)
 #undef AM_SET_LDS
@@ -1225,6 +1333,15 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
         const size_t lds = sizeof(float2) << pl.logN2;
         hipLaunchKernelGGL(k2_rows_gen<false>, grid, dim3(kFftThreads), lds, st, work, hc, dst, pl);
     }
+    return hipGetLastError();
+}
+
+bool plan_k2_has_group(const PlanDev& pl) { return plan_k2_is_r16(pl) && g_k2_variant == 0; }
+
+hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const K2Group& grp, const PlanDev& pl) {
+    if (!plan_k2_has_group(pl) || grp.n < 1 || grp.n > kMaxNeedleGroup) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k2_rows_r16_group, dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, grp, pl,
+                       (unsigned)npairs);
     return hipGetLastError();
 }
 

@@ -52,6 +52,16 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
                      bool half = false, float hscale = 1.0f);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
+// A group of needles sharing one forward row transform (r16 rows, f32 storage only):
+// needle j multiplies with hc[j] and writes its inverse rows to dst[j].
+constexpr int kMaxNeedleGroup = 8;
+struct K2Group {
+    const float2* hc[kMaxNeedleGroup];
+    float2* dst[kMaxNeedleGroup];
+    int n;
+};
+bool plan_k2_has_group(const PlanDev& pl);
+hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const K2Group& grp, const PlanDev& pl);
 // The score scan fused into K3 (r16 plan only).  stats32 == nullptr disables it
 // (plain correlation: every score is written).
 struct ScanCfg {

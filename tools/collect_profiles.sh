@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collects the evidence kept under profiles/: bench line, rocprofv3 kernel-trace stats of the same
+# command, and the two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace domains).
+# Run on the GPU box from the repo root:  tools/collect_profiles.sh gpurun_out/<tag>
+set -o pipefail
+out=${1:-gpurun_out/prof}
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 bench.py --no-cpu-baseline > "$out/stats.log" 2>&1 || exit 1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$out/pmc/$c" -o run -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --ramp-steps 0 > "$out/pmc_$c.log" 2>&1 || exit 1
+done
+python3 tools/pmc_summary.py "$out/pmc" "$out/pmc_traffic.json" > "$out/pmc_summary.log" 2>&1
+find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
+python3 tools/extra_bench.py > "$out/extra.json" 2> "$out/extra.err"
+python3 tools/multi_bench.py 8 1,4,8 > "$out/multi.json" 2> "$out/multi.err"
+echo collected

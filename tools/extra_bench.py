@@ -29,7 +29,7 @@ for k in range(nh):
     hays.append(b)
 algo.match_batch_device([b.ptr for b in hays], [h] * nh, p)
 t0 = time.perf_counter()
-reps = 3
+reps = 10
 for _ in range(reps):
     res = algo.match_batch_device([b.ptr for b in hays], [h] * nh, p)
 dt = (time.perf_counter() - t0) / reps
@@ -43,7 +43,7 @@ algos = [am.HipConvolve.from_device(dev, n.ptr, s) for n in needles]
 hay = am.synth_uniform_device(dev, h, 1, 1)
 for k, n in enumerate(needles):
     for t in (310 * SR + 1000 * k, 2010 * SR + 999 * k): am.axpy_device(dev, hay, t, n.ptr, s, 1.0)
-am.match_multi_device(algos, hay.ptr, h, p)
+for _ in range(5): am.match_multi_device(algos, hay.ptr, h, p)   # clock ramp
 t0 = time.perf_counter()
 for _ in range(reps):
     res = am.match_multi_device(algos, hay.ptr, h, p)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 shape on one GPU: NN needles against one resident 1 h haystack through
+am_match_multi_device, for several needle_group settings, with the per-kernel breakdown."""
+import json
+import sys
+import time
+
+sys.path.insert(0, "audio-matcher_amd/python"); sys.path.insert(0, "audio-matcher_amd")
+import audiomatch_amd as am
+
+dev = 0
+SR = 44100; s = 10 * SR; h = 3600 * SR
+nn = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+groups = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+cfg = am.Config(chunk_size_s=60, overlap_length_s=10, distance_s=480.0, prominence=0.13)
+p = cfg.params(SR, am.Scale.LIB)
+needles = [am.synth_uniform_device(dev, s, 1, 2001 + k) for k in range(nn)]
+algos = [am.HipConvolve.from_device(dev, n.ptr, s) for n in needles]
+hay = am.synth_uniform_device(dev, h, 1, 1)
+for k, n in enumerate(needles):
+    for t in (310 * SR + 1000 * k, 2010 * SR + 999 * k):
+        am.axpy_device(dev, hay, t, n.ptr, s, 1.0)
+out = {}
+KN = ("k1_cols_fwd", "k2_rows", "k3_cols_inv", "tile_stats", "peaks")
+for g in groups:
+    am.set_option("needle_group", g)
+    for _ in range(12):
+        res = am.match_multi_device(algos, hay.ptr, h, p)     # clock ramp + sparse-score state
+    assert all([q.start for q in r] == [310 * SR + 1000 * k, 2010 * SR + 999 * k] for k, r in enumerate(res))
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        am.match_multi_device(algos, hay.ptr, h, p)
+    dt = (time.perf_counter() - t0) / reps
+    with am.Profile(dev) as prof:
+        for _ in range(3):
+            am.match_multi_device(algos, hay.ptr, h, p)
+        kern = {n: round(prof.query(n)[0] / 3, 4) for n in KN}
+    out[f"group{g}"] = {"needle_samples_per_s": nn * h / dt, "ms_per_needle_hour": dt / nn * 1e3, "kernel_ms_per_call": kern}
+print(json.dumps(out, indent=1))
