@@ -52,7 +52,7 @@ static long long g_opt_pairs_per_group = 64;
 static long long g_opt_profile_mask = -1;    // bit i = bracket kernel class i with events while profiling is on
 static long long g_opt_lanes = 1;           // 2 = overlap the kernels of alternate pair groups on two streams
 static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
-static long long g_opt_needle_group = 4;    // needles sharing one forward row transform in am_match_multi_device
+static long long g_opt_needle_group = 8;    // needles sharing one forward row transform in am_match_multi_device
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;

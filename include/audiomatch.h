@@ -87,6 +87,13 @@ int am_device_count(int* n);
  * on their next use).  Optional: everything is also released at process exit. */
 int am_shutdown(void);
 
+/* Device pointers (every `d_` argument, and everything the `_device` entry
+ * points take): the library works on a stream of its own, which is NOT ordered
+ * with the caller's streams or with the null stream.  Data behind a device
+ * pointer must be complete before the call (synchronise whatever produced it;
+ * note that a device-to-device hipMemcpy returns before the copy has run), and
+ * results written to a device pointer are complete when the call returns. */
+
 /* ---- needle handle ----------------------------------------------------- */
 /* LibConvolve::new(sample_data) audio_matcher.rs:289 / MyConvolve::new :396.
  * `needle` is host memory, copied; the handle lives on `device`. */

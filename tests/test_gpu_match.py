@@ -270,7 +270,7 @@ def test_multi_needle_shared_forward_pass(gpu, oracle):
                 for g, o in zip(got, one):
                     assert abs(g.height - o.height) < 2e-6 and abs(g.prominence - o.prominence) < 2e-6, group
     finally:
-        gpu.set_option("needle_group", 4)
+        gpu.set_option("needle_group", 8)
     with pytest.raises(gpu.AudioMatchError):
         gpu.match_multi_device([algos[0], gpu.HipConvolve(needles[1][:-1])], buf.ptr, hay.size, p)
 
