@@ -159,8 +159,13 @@ __device__ __forceinline__ bool step_left(const float* __restrict__ g, const flo
             return false;
         }
     }
+    // A raw step stops at the start of the current 32-score run when run summaries
+    // exist: the walk is then aligned for the run-level skip above (raw steps of 64
+    // would keep the misalignment they started with all the way to the tile edge).
+    const long long run_lo = (cur - 1) & ~31ll;
+    const long long lo2 = (sp.stats32 != nullptr && run_lo > lo) ? run_lo : lo;
     const long long idx = cur - 1 - lane;
-    const bool valid = idx >= lo;
+    const bool valid = idx >= lo2;
     const float v = valid ? score_for_min(g, sp, idx) : 0.0f;
     const unsigned long long higher = __ballot(valid && v > h);
     const int nval = __popcll(__ballot(valid));
@@ -221,8 +226,11 @@ __device__ __forceinline__ bool step_right(const float* __restrict__ g, const fl
             return false;
         }
     }
+    // as in step_left: end a raw step at the next run boundary when run summaries exist
+    const long long run_hi = ((cur >> 5) + 1) << 5;
+    const long long hi2 = (sp.stats32 != nullptr && run_hi < hi) ? run_hi : hi;
     const long long idx = cur + lane;
-    const bool valid = idx < hi;
+    const bool valid = idx < hi2;
     const float v = valid ? score_for_min(g, sp, idx) : 0.0f;
     const unsigned long long higher = __ballot(valid && v > h);
     const int nval = __popcll(__ballot(valid));

@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_report_header(config):
+    """Which physical GPU ran the tests (rocm-smi unique id), for telling a code problem
+    from a machine problem when a run differs from the others."""
+    import shutil
+    import subprocess
+    smi = shutil.which("rocm-smi")
+    if not smi:
+        return None
+    try:
+        out = subprocess.run([smi, "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return None
+    ids = [ln.split(":")[-1].strip() for ln in out.splitlines() if "Unique ID" in ln and "0x" in ln]
+    return "gpu unique id(s): " + (", ".join(ids) if ids else "none visible")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import pyoracle

@@ -107,6 +107,19 @@ def test_random_wide_plan(gpu, oracle, seed):
     compare(gpu, oracle, needle, hay, sr, chunk, s, 0.13, float(rng.choice([5.0, 480.0])))
     # level 1 on the same plan
     win = hay[: s + 3_000_000]
-    got = gpu.HipConvolve(needle).correlate_with_sample(win, gpu.Mode.Valid, True)
+    algo = gpu.HipConvolve(needle)
+    got = algo.correlate_with_sample(win, gpu.Mode.Valid, True)
     ref = oracle.correlate(win, needle, oracle.MODE_VALID, oracle.SCALE_LIB)
-    assert np.abs(got - ref).max() < TOL
+    bad = np.nonzero(np.abs(got - ref) >= TOL)[0]
+    if bad.size:   # diagnostics: is the error tied to the handle (its spectrum) or to that one call?
+        again = algo.correlate_with_sample(win, gpu.Mode.Valid, True)
+        fresh = gpu.HipConvolve(needle).correlate_with_sample(win, gpu.Mode.Valid, True)
+        err = np.abs(got - ref)
+        cols = np.unique(bad % 16384)
+        percol = {int(c): float(err[c::16384].max()) for c in cols[:8]}
+        raise AssertionError((bad.size, bad[:6].tolist(), float(err.max()), s, h,
+                              "same handle again: max err %.3e" % float(np.abs(again - ref).max()),
+                              "fresh handle: max err %.3e" % float(np.abs(fresh - ref).max()),
+                              "bad columns", cols[:16].tolist(), percol,
+                              "errors >= 2e-5: %d" % int((err >= 2e-5).sum()),
+                              "cols >= 2e-5", np.unique(np.nonzero(err >= 2e-5)[0] % 16384)[:40].tolist()))
