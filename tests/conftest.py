@@ -16,20 +16,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
-def pytest_report_header(config):
-    """Which physical GPU ran the tests (rocm-smi unique id), for telling a code problem
-    from a machine problem when a run differs from the others."""
+def gpu_identity():
+    """Which physical GPU runs the tests (rocm-smi unique id), for telling a code problem
+    from a machine problem when one run differs from the others."""
     import shutil
     import subprocess
     smi = shutil.which("rocm-smi")
     if not smi:
-        return None
+        return "gpu unique id(s): rocm-smi not found"
     try:
         out = subprocess.run([smi, "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
     except Exception:
-        return None
+        return "gpu unique id(s): rocm-smi failed"
     ids = [ln.split(":")[-1].strip() for ln in out.splitlines() if "Unique ID" in ln and "0x" in ln]
     return "gpu unique id(s): " + (", ".join(ids) if ids else "none visible")
+
+
+def pytest_report_header(config):
+    return gpu_identity()
 
 
 @pytest.fixture(scope="session")
@@ -53,4 +57,5 @@ def amlib():
 def gpu(amlib):
     if amlib.device_count() < 1:
         pytest.fail("no HIP device visible: -m gpu tests need a real MI355X (no CPU fallback exists)")
+    amlib.gpu_identity = gpu_identity()   # quoted by tests whose failure may be the machine's
     return amlib

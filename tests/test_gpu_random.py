@@ -117,7 +117,7 @@ def test_random_wide_plan(gpu, oracle, seed):
         err = np.abs(got - ref)
         cols = np.unique(bad % 16384)
         percol = {int(c): float(err[c::16384].max()) for c in cols[:8]}
-        raise AssertionError((bad.size, bad[:6].tolist(), float(err.max()), s, h,
+        raise AssertionError((getattr(gpu, "gpu_identity", "?"), bad.size, bad[:6].tolist(), float(err.max()), s, h,
                               "same handle again: max err %.3e" % float(np.abs(again - ref).max()),
                               "fresh handle: max err %.3e" % float(np.abs(fresh - ref).max()),
                               "bad columns", cols[:16].tolist(), percol,
