@@ -62,17 +62,28 @@ __global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, l
     }
 }
 
-// level-1 summary (1024 scores) from K3's level-0 summary (32 scores): one
-// 32-lane half wave per tile
+// level-1 summary (1024 scores) from K3's level-0 summary (32 scores): eight lanes
+// per tile, each with four consecutive entries (two 16-byte loads)
 __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s32, long long n32,
                                                     float2* __restrict__ stats, long long ntiles) {
-    const long long tile = ((long long)blockIdx.x * 256 + threadIdx.x) >> 5;
-    const int l = threadIdx.x & 31;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tile = gid >> 3;
+    const int l = threadIdx.x & 7;
     float mn = FLT_MAX, mx = -FLT_MAX;
-    const long long idx = tile * 32 + l;
-    if (tile < ntiles && idx < n32) { const float2 v = s32[idx]; mn = v.x; mx = v.y; }
+    const long long idx = tile * 32 + 4 * l;
+    if (tile < ntiles) {
+        if (idx + 3 < n32) {
+            const float4 a = *reinterpret_cast<const float4*>(s32 + idx);
+            const float4 b = *reinterpret_cast<const float4*>(s32 + idx + 2);
+            mn = fminf(fminf(a.x, a.z), fminf(b.x, b.z));
+            mx = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w));
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (idx + k < n32) { const float2 v = s32[idx + k]; mn = fminf(mn, v.x); mx = fmaxf(mx, v.y); }
+        }
+    }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    for (int o = 4; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
     if (l == 0 && tile < ntiles) stats[tile] = make_float2(mn, mx);
 }
 
@@ -484,7 +495,7 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
     const long long n32 = (n + 31) / 32;
     const long long tiles = (n + kTile - 1) / kTile;
     if (tiles <= 0) return hipSuccess;
-    const long long blocks = (tiles * 32 + 255) / 256;
+    const long long blocks = (tiles * 8 + 255) / 256;
     hipLaunchKernelGGL(stats_reduce, dim3((unsigned)blocks), dim3(256), 0, st, stats32, n32, stats, tiles);
     return hipGetLastError();
 }
