@@ -138,9 +138,11 @@ int am_match_batch_device(const am_needle* h, const float* const* d_haystacks, c
 
 /* Several needles (equal length, same device) against one resident haystack
  * (BASELINE config 4): the haystack's forward column pass is computed once and
- * shared; out holds cap_per_needle slots per needle, n_out[k] the count for
- * needle k.  The reference has no such entry point (one snippet per run,
- * matcher/mod.rs:29-34); results equal n_needles separate am_match_device calls. */
+ * its forward row transforms once per group of needles (option "needle_group");
+ * out holds cap_per_needle slots per needle, n_out[k] the count for needle k.
+ * The reference has no such entry point (one snippet per run,
+ * matcher/mod.rs:29-34); offsets equal those of n_needles separate
+ * am_match_device calls, heights and prominences agree to f32 rounding. */
 int am_match_multi_device(const am_needle* const* needles, size_t n_needles, const float* d_haystack, size_t len,
                           const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out);
 
@@ -203,7 +205,10 @@ int am_profile_reset(int device);
 int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t* launches);
 
 /* options:
- *   "log_n" (0 = auto), "pairs_per_group", "k2_variant" (0/1): tuning knobs
+ *   "log_n" (0 = auto), "pairs_per_group", "k2_variant" (0/1), "lanes" (1/2),
+ *       "profile_mask": tuning / measurement knobs
+ *   "needle_group" (1..8, default 8): how many needles of am_match_multi_device share
+ *       one forward row transform of the haystack (1 = one row pass per needle)
  *   "half_pipeline" (0/1): store the transform's work matrix in half precision
  *       (BASELINE config 5).  Butterflies stay f32; scores then carry an absolute
  *       error of about 1e-5 of the chunk's score range, hit offsets are unaffected. */
