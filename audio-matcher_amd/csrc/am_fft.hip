@@ -283,7 +283,7 @@ __device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float
 }
 
 template <int KIND, bool HALF>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 3)
 k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
     const int t = threadIdx.x;
