@@ -52,6 +52,7 @@ static long long g_opt_pairs_per_group = 64;
 static long long g_opt_profile_mask = -1;    // bit i = bracket kernel class i with events while profiling is on
 static long long g_opt_lanes = 1;           // 2 = overlap the kernels of alternate pair groups on two streams
 static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
+static long long g_opt_batch_overlap = 1;   // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
 static long long g_opt_needle_group = 8;    // needles sharing one forward row transform in am_match_multi_device
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
@@ -107,6 +108,10 @@ struct Ctx {
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
     DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum;
+    // second set of the score-side buffers: in a batch the peak pick of haystack k runs on
+    // stream2 beside the transforms of haystack k+1, which then need their own set
+    DevBuf scores_b, stats_b, stats32_b, wflags_b, peaks_b;
+    hipEvent_t ev_k3[2] = {nullptr, nullptr}, ev_pick[2] = {nullptr, nullptr};
     HostBuf pinned;
     // Per-chunk result headers live in coherent pinned host memory that the peak
     // kernel writes directly (a few KB per haystack): no device-to-host copy
@@ -146,6 +151,10 @@ static int get_ctx(int device, Ctx** out) {
     (void)hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventCreateWithFlags(&c->ev_k3[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->ev_pick[i], hipEventDisableTiming);
+    }
     g_ctx[device] = c;
     *out = c;
     return AM_OK;
@@ -319,6 +328,8 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
 struct ScanRequest {
     float theta;             // in: raw-score write threshold
     long long seg_c, seg_d;  // in: chunk geometry (scores i*seg_c .. i*seg_c + seg_d)
+    int set;                 // in: which set of score-side buffers (0, or 1 in an overlapped batch)
+    hipEvent_t before_k3;    // in: K3 must not overwrite that set before this event (or null)
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
@@ -346,10 +357,12 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
         scan_req->fused = false;
         scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
         if (plan_is_r16(pl->dev) && (hop % kTile) == 0) {
-            if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-            if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;
-            scan.stats32 = (float2*)c->stats32.p;
-            scan.wflags = (unsigned char*)c->wflags.p;
+            DevBuf& b32 = scan_req->set ? c->stats32_b : c->stats32;
+            DevBuf& bwf = scan_req->set ? c->wflags_b : c->wflags;
+            if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
+            if ((rc = bwf.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;
+            scan.stats32 = (float2*)b32.p;
+            scan.wflags = (unsigned char*)bwf.p;
             scan.theta = scan_req->theta;
             scan.seg_c = scan_req->seg_c;
             scan.seg_d = scan_req->seg_d;
@@ -373,6 +386,7 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
             job.first_pair = (int)first;
             { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
             { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
+            if (first == 0 && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
             { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
         }
         return AM_OK;
@@ -470,24 +484,29 @@ static int upload_segments(Ctx* c, const std::vector<Segment>& segs) {
 // resident score array; segment descriptors and result headers live at
 // [seg_off, seg_off + nsegs) of the context's segment / header buffers.
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
-                       float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off = -1) {
+                       float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off = -1,
+                       hipStream_t st = nullptr) {
     if (hdr_off < 0) hdr_off = seg_off;
+    if (!st) st = c->stream;
+    const int set = scan ? scan->set : 0;
+    DevBuf& bstats = set ? c->stats_b : c->stats;
+    DevBuf& bpeaks = set ? c->peaks_b : c->peaks;
     const float2* d_stats32 = (scan && scan->fused) ? scan->sparse.stats32 : nullptr;
     const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;
-    if ((rc = c->stats.ensure((size_t)ntiles * sizeof(float2)))) return rc;
+    if ((rc = bstats.ensure((size_t)ntiles * sizeof(float2)))) return rc;
     {
-        ProfScope ps(c, KN_STATS);
-        if (d_stats32) AM_HIP(launch_stats_reduce(c->stream, d_stats32, n_scores, (float2*)c->stats.p));
-        else AM_HIP(launch_tile_stats(c->stream, d_scores, n_scores, (float2*)c->stats.p));
+        ProfScope ps(c, KN_STATS, st);
+        if (d_stats32) AM_HIP(launch_stats_reduce(st, d_stats32, n_scores, (float2*)bstats.p));
+        else AM_HIP(launch_tile_stats(st, d_scores, n_scores, (float2*)bstats.p));
     }
     {
-        ProfScope ps(c, KN_PEAKS);
-        AM_HIP(launch_peaks(c->stream, d_scores, n_scores, (const float2*)c->stats.p,
+        ProfScope ps(c, KN_PEAKS, st);
+        AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p + hdr_off, sp));
+                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp));
     }
     return AM_OK;
 }
@@ -563,22 +582,47 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         return fail(AM_ERR_INVALID_ARG, "chunk size too small for this haystack (more than 2^18 chunks)");
     int rc;
     const size_t hdr_bytes = sizeof(SegHeader) * nsegs;
+    // In a batch the peak pick of haystack k (small, latency-bound kernels) runs on a second
+    // stream beside the transforms of haystack k+1; the score-side buffers alternate between
+    // two sets and K3 waits for the pick that last read the set it is about to overwrite.
+    size_t n_active = 0;
+    for (size_t k = 0; k < n_hay; ++k) n_active += seg_off[k + 1] > seg_off[k];
+    const bool overlap = g_opt_batch_overlap && n_active > 1 && g_opt_lanes != 2 && c->stream2 &&
+                         c->ev_k3[0] && c->ev_k3[1] && c->ev_pick[0] && c->ev_pick[1];
     if ((rc = c->scores.ensure(max_scores * sizeof(float)))) return rc;
     if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    if (overlap) {
+        if ((rc = c->scores_b.ensure(max_scores * sizeof(float)))) return rc;
+        if ((rc = c->peaks_b.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    }
     if ((rc = upload_segments(c, segs))) return rc;
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
+    size_t seq = 0;
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
         if (g_progress_fn) g_progress_fn(g_progress_user, k, 0, (size_t)ns);
         const long long out_count = (long long)(lens[k] - s + 1);
-        if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
+        const int set = overlap ? (int)(seq & 1) : 0;
+        float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
+        scan.set = set;
+        scan.before_k3 = (overlap && seq >= 2) ? c->ev_pick[set] : nullptr;
+        if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, d_scores, out_count, factor,
                                   &scan, src_kind))) return rc;
-        if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, seg_off[k], ns, p->min_prominence,
-                              (long long)p->min_distance, &scan))) return rc;
+        if (overlap) {
+            AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
+            AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
+        }
+        if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence,
+                              (long long)p->min_distance, &scan, -1, overlap ? c->stream2 : c->stream))) return rc;
+        if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
+        ++seq;
     }
     AM_HIP(hipStreamSynchronize(c->stream));   // the headers are in host memory once the peak kernels have finished
+    if (overlap) AM_HIP(hipStreamSynchronize(c->stream2));
+    scan.set = 0;
+    scan.before_k3 = nullptr;
     int worst = AM_OK;
     std::vector<am_peak> all;
     for (size_t k = 0; k < n_hay; ++k) {
@@ -1133,6 +1177,7 @@ int am_shutdown(void) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
+                          &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b,
                           &c->peaks, &c->io_in, &c->io_out, &c->sum})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
@@ -1195,6 +1240,7 @@ int am_set_option(const char* key, long long value) {
         g_opt_log_n = value; return AM_OK;
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
         if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
         g_opt_needle_group = value; return AM_OK;
@@ -1221,6 +1267,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
     if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
     if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
+    if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "lanes")) { *value = g_opt_lanes; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
