@@ -59,12 +59,45 @@ static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
 
 // ---------------------------------------------------------------------------
+static long long g_opt_vmm = 0;   // experiment: back the work matrix with hipMemCreate chunks (see DevBuf)
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int ensure(size_t bytes) {
+    // EXPERIMENT (option "vmm_work"): virtual-memory-management allocation, one physical
+    // handle per `chunk` bytes, to see whether the physical fragment size behind the work
+    // matrix explains the two speeds K1/K3 show from process to process.
+    bool vmm = false;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    size_t vmm_chunk = 0;
+    int ensure_vmm(size_t bytes, int device) {
+        release();
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        AM_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        const size_t chunk = std::max<size_t>(gran, (size_t)g_opt_vmm << 20);
+        const size_t total = (bytes + chunk - 1) / chunk * chunk;
+        AM_HIP(hipMemAddressReserve(&p, total, chunk, nullptr, 0));
+        for (size_t off = 0; off < total; off += chunk) {
+            hipMemGenericAllocationHandle_t hnd;
+            AM_HIP(hipMemCreate(&hnd, chunk, &prop, 0));
+            handles.push_back(hnd);
+            AM_HIP(hipMemMap(static_cast<char*>(p) + off, chunk, 0, hnd, 0));
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        AM_HIP(hipMemSetAccess(p, total, &acc, 1));
+        vmm = true; vmm_chunk = chunk; cap = total;
+        return AM_OK;
+    }
+    int ensure(size_t bytes, int vmm_device = -1) {
         if (bytes <= cap) return AM_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (vmm_device >= 0 && g_opt_vmm > 0) return ensure_vmm(bytes + bytes / 8, vmm_device);
+        release();
         size_t want = bytes + bytes / 8;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
@@ -75,7 +108,18 @@ struct DevBuf {
         cap = want;
         return AM_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() {
+        if (p && vmm) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemUnmap(p, cap);
+            for (auto hnd : handles) (void)hipMemRelease(hnd);
+            (void)hipMemAddressFree(p, cap);
+            handles.clear();
+        } else if (p) {
+            (void)hipFree(p);
+        }
+        p = nullptr; cap = 0; vmm = false;
+    }
 };
 struct HostBuf {
     void* p = nullptr;
@@ -351,7 +395,7 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
     const long long npairs = (nblocks + 1) / 2;
     long long ppg = std::max<long long>(1, g_opt_pairs_per_group);
     if (ppg > npairs) ppg = npairs;
-    if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
+    if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2), c->device))) return rc;
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
@@ -1241,6 +1285,7 @@ int am_set_option(const char* key, long long value) {
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "vmm_work")) { g_opt_vmm = value < 0 ? 0 : value; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
         if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
         g_opt_needle_group = value; return AM_OK;
