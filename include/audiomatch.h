@@ -207,6 +207,10 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
 /* options:
  *   "log_n" (0 = auto), "pairs_per_group", "k2_variant" (0/1), "lanes" (1/2),
  *       "profile_mask": tuning / measurement knobs
+ *   "batch_overlap" (0/1, default 1): in am_match_batch_device pick the peaks of haystack k
+ *       on a second stream beside the transforms of haystack k+1
+ *   "vmm_work" (0 = off, else MB per physical chunk): measurement only; backs the work
+ *       matrix with hipMemCreate chunks of that size (fragment size)
  *   "needle_group" (1..8, default 8): how many needles of am_match_multi_device share
  *       one forward row transform of the haystack (1 = one row pass per needle)
  *   "half_pipeline" (0/1): store the transform's work matrix in half precision
