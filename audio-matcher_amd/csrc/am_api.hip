@@ -355,12 +355,14 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
     Job job{};
     job.src = h->d_needle; job.src_len = (long long)h->n; job.lead = 0;
     job.dst = nullptr; job.out_count = 0; job.hop = 1; job.nblocks = 1; job.first_pair = 0;
+    hipError_t e;
     {
         ProfScope ps(c, KN_OTHER);
-        AM_HIP(launch_k1(c->stream, job, 1, (float2*)c->work.p, pl->dev));
-        AM_HIP(launch_k2_spectrum(c->stream, (float2*)c->work.p, hc, pl->dev));
+        e = launch_k1(c->stream, job, 1, (float2*)c->work.p, pl->dev);
+        if (e == hipSuccess) e = launch_k2_spectrum(c->stream, (float2*)c->work.p, hc, pl->dev);
     }
-    AM_HIP(hipStreamSynchronize(c->stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(hc); return hip_fail(e, "needle spectrum"); }
     h->spectra[key] = hc;
     *out = hc;
     return AM_OK;
