@@ -15,4 +15,5 @@ python3 tools/pmc_summary.py "$out/pmc" "$out/pmc_traffic.json" > "$out/pmc_summ
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
 python3 tools/extra_bench.py > "$out/extra.json" 2> "$out/extra.err"
 python3 tools/multi_bench.py 8 1,4,8 > "$out/multi.json" 2> "$out/multi.err"
+python3 tools/batch_bench.py 16 > "$out/batch.json" 2> "$out/batch.err"
 echo collected
