@@ -325,7 +325,9 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
         // N = 2^21 (256 x 8192) while at least 3/4 of a block is new output; N = 2^22
         // (256 x 2 x 8192, about 8 % dearer per point) for longer needles, up to 3 M
         // samples; beyond that the generic kernels at N = 2^23
-        if ((long long)s <= (1ll << 19)) { *logN_out = 21; return AM_OK; }
+        // measured crossover (tools/needle_sweep.py): 2^22 wins from about 10.5 s of 44.1 kHz audio
+        // (the half-precision work matrix exists on the 2^21 plan only: keep it there up to 2^19 samples)
+        if ((long long)s <= (g_opt_half ? (1ll << 19) : 7 * (1ll << 16))) { *logN_out = 21; return AM_OK; }
         if ((long long)s <= (1ll << 22) - (1ll << 20)) { *logN_out = 22; return AM_OK; }
     }
     int pref = min_log;
