@@ -346,6 +346,42 @@ def test_error_codes(gpu):
     assert rc == gpu.AM_ERR_CAPACITY and n.value == 4
 
 
+@pytest.mark.timeout(120)
+def test_degenerate_signals_terminate(gpu, oracle):
+    """Inputs the reference would choke on must not hang or crash the device: a silent
+    haystack (every score exactly 0: one plateau, no peak), a silent needle (energy 0:
+    every scaled score is NaN) and a haystack with NaNs / infinities in one place.  Those
+    poison the PAIR of overlap-save blocks that holds them (two blocks share one complex
+    transform), i.e. up to 2 x hop scores, where the reference loses one chunk; hits beyond
+    that pair are still found."""
+    sr = 44100
+    s = 2 * sr
+    needle = oracle.synth_uniform(5, 0, 0, s)
+    cfg = gpu.Config(chunk_size_s=10.0, overlap_length_s=2.0, distance_s=5.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    # both plans: the register kernels (span > 2^19) and the generic ones
+    for h in (400 * sr, 9 * sr):
+        silent = np.zeros(h, np.float32)
+        for _ in range(2):                       # dense, then sparse score path
+            assert algo.match(silent, p) == []
+        hay = oracle.synth_uniform(5, 1, 0, h)
+        off = h - 4 * sr
+        hay[off:off + s] += needle
+        bad = hay.copy()
+        bad[1000] = np.nan
+        bad[1001] = np.inf
+        bad[1002] = -np.inf
+        for _ in range(2):
+            got = algo.match(bad, p)
+            assert isinstance(got, list)
+            if h > 40 * sr:                      # the poisoned blocks end long before the hit
+                assert off in [g.start for g in got]
+    zero = gpu.HipConvolve(np.zeros(s, np.float32))
+    for _ in range(2):
+        assert isinstance(zero.match(oracle.synth_uniform(5, 2, 0, 30 * sr), p), list)
+
+
 def test_half_pipeline_config5(gpu, oracle):
     """BASELINE config 5: 48 kHz interleaved i16 stereo through the half-precision
     pipeline (work matrix stored as f16).  SURVEY 7: offset parity is the promise;
