@@ -108,3 +108,26 @@ def test_batch_equals_singles_full_size(full):
     assert [q.start for q in res[0]] == plant_offsets(0)
     assert [q.start for q in res[1]] == plant_offsets(1)
     assert [(q.start, q.height) for q in res[2]] == [(q.start, q.height) for q in res[0]]
+
+
+def test_offsets_beyond_2_to_31_samples(gpu):
+    """A 14 h haystack (2.22e9 samples, 8.9 GB resident): score indices, block and chunk
+    arithmetic beyond 2^31, hits before and after that mark, found on the dense and the
+    sparse score path."""
+    hours = 14
+    n = hours * H
+    assert n > 2 ** 31
+    needle = gpu.synth_uniform_device(0, S, seed=1, stream=0)
+    algo = gpu.HipConvolve.from_device(0, needle.ptr, S)
+    hay = gpu.synth_uniform_device(0, n, seed=7, stream=3)
+    # more than the 480 s overshadow distance apart (audio_matcher.rs:143-160)
+    plants = [12_345, 2 ** 31 - S // 2, 2 ** 31 + 600 * SR + 3, n - S - 17]
+    for t in plants:
+        gpu.axpy_device(0, hay, t, needle.ptr, S, 1.0)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=480.0, prominence=0.13)
+    p = cfg.params(SR, gpu.Scale.LIB)
+    for _ in range(2):
+        got = algo.match_device(hay.ptr, n, p)
+        assert [q.start for q in got] == plants
+        assert all(abs(q.height - 1.0) < 0.02 and q.end == q.start + 1 for q in got)
+    hay.free()
