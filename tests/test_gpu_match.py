@@ -108,6 +108,36 @@ def test_device_resident_and_batch(gpu, oracle):
     assert [x.start for x in res[1]] == [int(12.5 * sr)]
 
 
+def test_ragged_batch_with_and_without_overlap(gpu, oracle):
+    """The per-file loop over resident haystacks of very different lengths, including one
+    shorter than the needle and one of exactly the needle's length: every entry equals the
+    single call, with the peak pick overlapped (two buffer sets, second stream) or not."""
+    sr = 44100
+    needle = oracle.synth_uniform(17, 0, 0, 3 * sr)
+    secs = [200.0, 1.5, 90.0, 3.0, 333.3, 47.0, 200.0, 12.0]
+    hays = []
+    for k, t in enumerate(secs):
+        h = oracle.synth_uniform(17, 10 + k, 0, int(t * sr))
+        if t > 20:
+            for off in (int(0.31 * t * sr), int(0.77 * t * sr)):
+                h[off:off + needle.size] += needle
+        hays.append(h)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=3.0, distance_s=10.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in hays]
+    singles = [algo.match_device(b.ptr, h.size, p) for b, h in zip(bufs, hays)]
+    key = lambda r: [(q.start, q.end, q.height, q.prominence) for q in r]
+    assert singles[1] == [] and [len(r) for r in singles] == [2, 0, 2, 0, 2, 2, 2, 0]
+    try:
+        for mode in (1, 0, 1):
+            gpu.set_option("batch_overlap", mode)
+            res = algo.match_batch_device([b.ptr for b in bufs], [h.size for h in hays], p)
+            assert [key(r) for r in res] == [key(r) for r in singles], mode
+    finally:
+        gpu.set_option("batch_overlap", 1)
+
+
 def test_synth_generator_matches_oracle_bitwise(gpu, oracle):
     n = 100_003
     buf = gpu.synth_uniform_device(0, n, seed=3, stream=17, first=12345, amp=0.25)
