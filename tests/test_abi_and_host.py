@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -107,3 +108,17 @@ def test_host_rows_selftest():
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "selftest ok" in out.stdout
+
+
+def test_bench_and_smoke_refuse_to_run_without_a_gpu(amlib):
+    """No CPU fallback anywhere on the product path: without a HIP device bench.py and
+    smoke() stop with an explicit error instead of producing a number."""
+    import subprocess
+    if amlib.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+                        "--ramp-steps", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs a HIP device" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs a HIP device" in r.stderr
