@@ -50,6 +50,13 @@ extern "C" {
         h: *const AmNeedle, haystack: *const f32, len: usize, p: *const AmMatchParams,
         out: *mut AmPeak, cap: usize, n_out: *mut usize,
     ) -> c_int;
+    /// interleaved i16 stereo frames, i.e. what minimp3 yields before the down-mix of
+    /// mp3_reader.rs:28-37 (the down-mix then happens inside the first kernel, bit-exact)
+    pub fn am_needle_create_pcm16(device: c_int, interleaved: *const i16, frames: usize, out: *mut *mut AmNeedle) -> c_int;
+    pub fn am_match_pcm16(
+        h: *const AmNeedle, interleaved: *const i16, frames: usize, p: *const AmMatchParams,
+        out: *mut AmPeak, cap: usize, n_out: *mut usize,
+    ) -> c_int;
 }
 
 /// audio_matcher.rs:55-59
@@ -82,6 +89,17 @@ impl HipConvolve {
             return Err(am_err(rc));
         }
         Ok(Self { h, len: sample_data.len() })
+    }
+
+    /// The same from decoded stereo PCM (`frame.data`, mp3_reader.rs:28): no CPU down-mix pass.
+    pub fn from_pcm16(interleaved: &[i16]) -> Result<Self, Box<dyn std::error::Error>> {
+        let mut h = std::ptr::null_mut();
+        let frames = interleaved.len() / 2;
+        let rc = unsafe { am_needle_create_pcm16(0, interleaved.as_ptr(), frames, &mut h) };
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        Ok(Self { h, len: frames })
     }
 
     /// CorrelateAlgo::inverse_sample_auto_correlation (audio_matcher.rs:66)
@@ -129,6 +147,24 @@ impl HipConvolve {
         if rc == AM_ERR_CAPACITY {
             buf.resize(n, AmPeak::default());
             rc = unsafe { am_match(self.h, m_samples.as_ptr(), m_samples.len(), &p, buf.as_mut_ptr(), buf.len(), &mut n) };
+        }
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        buf.truncate(n);
+        Ok(buf)
+    }
+
+    /// `calc_chunks` on decoded stereo PCM frames (interleaved i16, as minimp3 delivers them):
+    /// same result as down-mixing on the CPU first, one pass less over the haystack.
+    pub fn calc_chunks_pcm16(&self, p: &AmMatchParams, interleaved: &[i16]) -> Result<Vec<AmPeak>, Box<dyn std::error::Error>> {
+        let frames = interleaved.len() / 2;
+        let mut buf = vec![AmPeak::default(); 256];
+        let mut n = 0usize;
+        let mut rc = unsafe { am_match_pcm16(self.h, interleaved.as_ptr(), frames, p, buf.as_mut_ptr(), buf.len(), &mut n) };
+        if rc == AM_ERR_CAPACITY {
+            buf.resize(n, AmPeak::default());
+            rc = unsafe { am_match_pcm16(self.h, interleaved.as_ptr(), frames, p, buf.as_mut_ptr(), buf.len(), &mut n) };
         }
         if rc != AM_OK {
             return Err(am_err(rc));
