@@ -157,9 +157,18 @@ __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned v
     const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
     return make_float2(v.x, v.y);
 }
+// A 16-byte store reads its four data VGPRs over several cycles after issue.  hipcc (ROCm 7.2)
+// keeps the documented wait state before a VALU write of one of them only when the store has no
+// SGPR soffset; with one (all of ours: soff is a multiple of 4096) it may place the overwrite
+// directly behind the store, and on MI355X the last lanes of each 16-lane group then store the
+// NEW value of the upper dwords now and then (the intermittent wide-plan failure of DESIGN.md
+// section 3: `buffer_store_dwordx4 v[2:5], ..., s30 offen` followed by `v_sub_f32 v4, ...`).
+// The empty-looking asm reads the data registers after the store, so nothing can overwrite them
+// before two wait states have passed.  tools/check_store_hazard.py checks the ISA for this.
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
     f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
+    asm volatile("s_nop 1" : : "v"(o));
 }
 
 // Half-precision STORAGE of the work matrix (option "half_pipeline", BASELINE

@@ -122,3 +122,24 @@ def test_bench_and_smoke_refuse_to_run_without_a_gpu(amlib):
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs a HIP device" in r.stderr
+
+
+def test_isa_has_no_store_data_hazard(tmp_path):
+    """The gfx950 store-data hazard of DESIGN.md section 3: no >64-bit store in the compiled
+    kernels may have one of its data VGPRs overwritten after fewer than two wait states
+    (tools/check_store_hazard.py on the ISA hipcc emits for every HIP source)."""
+    sys.path.insert(0, os.path.join(ROOT, "audio-matcher_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build as am_build
+    import check_store_hazard as chk
+    from concurrent.futures import ThreadPoolExecutor
+
+    def emit(src):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.check_call([am_build._hipcc(), *[f for f in am_build.FLAGS if f != "-fPIC"], "--cuda-device-only", "-S",
+                               os.path.join(am_build.CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
+        return out
+    with ThreadPoolExecutor(max_workers=len(am_build.SOURCES)) as ex:
+        files = list(ex.map(emit, am_build.SOURCES))
+    found = [hit for f in files for hit in chk.check(f)]
+    assert found == [], found[:3]
