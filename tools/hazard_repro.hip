@@ -42,6 +42,35 @@ __global__ void __launch_bounds__(256) k(unsigned* out, unsigned n_per_block, in
     }
 }
 
+// the same with a global store (64-bit VGPR address), the form hipcc uses for plain float4 stores
+template <int NOPS>
+__global__ void __launch_bounds__(256) kg(unsigned* out, unsigned n_per_block, int rounds) {
+    unsigned* base = out + (size_t)blockIdx.x * n_per_block;
+    const unsigned poison = 0xDEADBEEFu;
+    for (int r = 0; r < rounds; ++r) {
+        unsigned* p = base + (threadIdx.x + 256u * (unsigned)r) * 4u;
+        const unsigned tag = blockIdx.x * 65536u + r * 256u + threadIdx.x;
+        asm volatile(
+            "v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n v_mov_b32 v12, %0\n v_mov_b32 v13, %0\n"
+            "s_nop 4\n"
+            "global_store_dwordx4 %1, v[10:13], off\n"
+            ".if %c3 == 1\n s_nop 0\n .endif\n .if %c3 == 2\n s_nop 1\n .endif\n"
+            "v_mov_b32 v12, %2\n v_mov_b32 v13, %2\n v_mov_b32 v10, %2\n v_mov_b32 v11, %2\n"
+            : : "v"(tag), "v"(p), "v"(poison), "n"(NOPS) : "v10", "v11", "v12", "v13", "memory");
+    }
+}
+template <int N> long rung(unsigned* d, std::vector<unsigned>& h, int blocks, int rounds, int reps) {
+    const unsigned n_per_block = 256u * 4u * (unsigned)rounds;
+    long bad = 0;
+    for (int i = 0; i < reps; ++i) {
+        (void)hipMemset(d, 0, h.size() * 4);
+        kg<N><<<blocks, 256>>>(d, n_per_block, rounds);
+        (void)hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t j = 0; j < h.size(); ++j) bad += h[j] == 0xDEADBEEFu;
+    }
+    return bad;
+}
+
 template <int S, int N> long run(unsigned* d, std::vector<unsigned>& h, int blocks, int rounds, int reps) {
     const unsigned n_per_block = 256u * 4u * (unsigned)rounds;
     long bad = 0;
@@ -65,5 +94,8 @@ int main() {
     printf("literal soffset 0, 0 wait states: %ld\n", run<0, 0>(d, h, blocks, rounds, reps));
     printf("literal soffset 0, 1 wait state : %ld\n", run<0, 1>(d, h, blocks, rounds, reps));
     printf("literal soffset 0, 2 wait states: %ld\n", run<0, 2>(d, h, blocks, rounds, reps));
+    printf("global_store_dwordx4, 0 wait states: %ld\n", rung<0>(d, h, blocks, rounds, reps));
+    printf("global_store_dwordx4, 1 wait state : %ld\n", rung<1>(d, h, blocks, rounds, reps));
+    printf("global_store_dwordx4, 2 wait states: %ld\n", rung<2>(d, h, blocks, rounds, reps));
     return 0;
 }
