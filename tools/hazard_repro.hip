@@ -59,6 +59,34 @@ __global__ void __launch_bounds__(256) kg(unsigned* out, unsigned n_per_block, i
             : : "v"(tag), "v"(p), "v"(poison), "n"(NOPS) : "v10", "v11", "v12", "v13", "memory");
     }
 }
+// 8-byte buffer store with an SGPR soffset, overwritten at once (the library's half-precision / 512-thread paths)
+__global__ void __launch_bounds__(256) k2(unsigned* out, unsigned n_per_block, int rounds) {
+    const unsigned long long base = (unsigned long long)(out + (size_t)blockIdx.x * n_per_block);
+    i32x4 rsrc;
+    rsrc.x = (int)(unsigned)base; rsrc.y = (int)(unsigned)(base >> 32); rsrc.z = (int)(n_per_block * 4u); rsrc.w = 0x00020000;
+    const unsigned poison = 0xDEADBEEFu, soff = 0u;
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned voff = (threadIdx.x + 256u * (unsigned)r) * 16u;
+        const unsigned tag = blockIdx.x * 65536u + r * 256u + threadIdx.x;
+        asm volatile(
+            "v_mov_b32 v10, %0\n v_mov_b32 v11, %0\n s_nop 4\n"
+            "buffer_store_dwordx2 v[10:11], %1, %2, %3 offen\n"
+            "v_mov_b32 v11, %4\n v_mov_b32 v10, %4\n"
+            : : "v"(tag), "v"(voff), "s"(rsrc), "s"(soff), "v"(poison) : "v10", "v11", "memory");
+    }
+}
+long run2(unsigned* d, std::vector<unsigned>& h, int blocks, int rounds, int reps) {
+    const unsigned n_per_block = 256u * 4u * (unsigned)rounds;
+    long bad = 0;
+    for (int i = 0; i < reps; ++i) {
+        (void)hipMemset(d, 0, h.size() * 4);
+        k2<<<blocks, 256>>>(d, n_per_block, rounds);
+        (void)hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t j = 0; j < h.size(); ++j) bad += h[j] == 0xDEADBEEFu;
+    }
+    return bad;
+}
+
 template <int N> long rung(unsigned* d, std::vector<unsigned>& h, int blocks, int rounds, int reps) {
     const unsigned n_per_block = 256u * 4u * (unsigned)rounds;
     long bad = 0;
@@ -94,6 +122,7 @@ int main() {
     printf("literal soffset 0, 0 wait states: %ld\n", run<0, 0>(d, h, blocks, rounds, reps));
     printf("literal soffset 0, 1 wait state : %ld\n", run<0, 1>(d, h, blocks, rounds, reps));
     printf("literal soffset 0, 2 wait states: %ld\n", run<0, 2>(d, h, blocks, rounds, reps));
+    printf("buffer_store_dwordx2, SGPR soffset, 0 wait states: %ld\n", run2(d, h, blocks, rounds, reps));
     printf("global_store_dwordx4, 0 wait states: %ld\n", rung<0>(d, h, blocks, rounds, reps));
     printf("global_store_dwordx4, 1 wait state : %ld\n", rung<1>(d, h, blocks, rounds, reps));
     printf("global_store_dwordx4, 2 wait states: %ld\n", rung<2>(d, h, blocks, rounds, reps));
