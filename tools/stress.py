@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""Repeat the full-size correlation / match many times and compare every result
-bit for bit with the first one (hunting for intermittent data races)."""
+"""Bit-for-bit repeatability loops (hunting for intermittent data races).
+
+  stress.py [iters] [mix] [opt=val ...]   full-size correlation / match repeated, every result
+                                          compared with the first one
+  stress.py alt [iters]                   two different inputs alternated through one handle on
+                                          one-pair problems of every plan family (whole working
+                                          set in the L2s): a stale line or a lost store between
+                                          kernels shows as pieces of the other input's data
+"""
 import ctypes as C
 import os
 import sys
@@ -20,7 +27,33 @@ def plant_offsets(k):
     return [600 * SR * m + 30 * SR + 17 * k + 1234 for m in range(6)]
 
 
+def alternate(iters):
+    rng = np.random.default_rng(77)
+    cases = {"wide 2^22 (1 pair)": (900_001, 3_000_000), "r16 2^21 (1 pair)": (300_001, 1_500_000),
+             "r16 2^21 (2 pairs)": (300_001, 5_000_000), "generic 2^17": (20_001, 90_000)}
+    for name, (s, extra) in cases.items():
+        needle = rng.uniform(-0.25, 0.25, s).astype(np.float32)
+        ins = [rng.uniform(-0.25, 0.25, s + extra).astype(np.float32) for _ in range(2)]
+        a = am.HipConvolve(needle)
+        ref = [None, None]
+        bad = 0
+        for it in range(iters):
+            k = it & 1
+            got = a.correlate_with_sample(ins[k], am.Mode.Valid, True)
+            if ref[k] is None:
+                ref[k] = got
+            elif not np.array_equal(got, ref[k]):
+                bad += 1
+                d = np.nonzero(got != ref[k])[0]
+                print("  %s iter %d input %d: %d differ, idx %d..%d, max %.3e, cols(mod 16384) %s" %
+                      (name, it, k, d.size, d[0], d[-1], np.abs(got[d] - ref[k][d]).max(), np.unique(d % 16384)[:12]), flush=True)
+        a.close()
+        print("%-22s %d iterations, %d mismatches" % (name, iters, bad), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "alt":
+        return alternate(int(sys.argv[2]) if len(sys.argv) > 2 else 300)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     mix = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     for kv in sys.argv[3:]:
