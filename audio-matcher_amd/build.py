@@ -63,6 +63,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """A/B builds for tools/ab.sh: the library with extra -D flags, as build/variants/<name>.so."""
+    vdir = os.path.join(OBJ, "variants")
+    odir = os.path.join(OBJ, "variants_obj", name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(odir, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    for s_ in SOURCES:
+        obj = os.path.join(odir, s_ + ".o")
+        subprocess.check_call([hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, s_), "-o", obj])
+        objs.append(obj)
+    out = os.path.join(vdir, name + ".so")
+    subprocess.check_call([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, *objs])
+    return out
+
+
 CLI = os.path.join(HERE, "bin", "audiomatch")
 HOST = os.path.join(HERE, "host")
 

@@ -10,6 +10,7 @@
 // All arithmetic on samples runs in the HIP kernels of am_fft.hip /
 // am_peaks.hip; there is no CPU fallback.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -17,6 +18,8 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <condition_variable>
 #include <vector>
 
 #include "am_kernels.h"
@@ -42,61 +45,46 @@ static int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #call);    \
     } while (0)
 
-// progress hook (audio_matcher.rs:102-117, 129)
-static am_progress_fn g_progress_fn = nullptr;
-static void* g_progress_user = nullptr;
+// progress hooks (audio_matcher.rs:102-117, 129); a call works on the snapshot it takes on entry
+struct Hooks {
+    am_progress_fn fn = nullptr;
+    void* user = nullptr;
+    am_chunk_progress_fn chunk_fn = nullptr;
+    void* chunk_user = nullptr;
+};
+static std::mutex g_hooks_mu;
+static Hooks g_hooks;
+static Hooks snapshot_hooks() {
+    std::lock_guard<std::mutex> lk(g_hooks_mu);
+    return g_hooks;
+}
 
-// tuning knobs
-static long long g_opt_log_n = 0;          // 0 = auto
-static long long g_opt_pairs_per_group = 64;
-static long long g_opt_profile_mask = -1;    // bit i = bracket kernel class i with events while profiling is on
-static long long g_opt_lanes = 1;           // 2 = overlap the kernels of alternate pair groups on two streams
-static long long g_opt_half = 0;            // 1 = half-precision storage of the work matrix (config 5)
-static long long g_opt_batch_overlap = 1;   // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
-static long long g_opt_needle_group = 8;    // needles sharing one forward row transform in am_match_multi_device
+// Process-wide option DEFAULTS (am_set_option).  Every entry point reads them once, on
+// entry, into an Opts value that the whole call then works with, so a concurrent
+// am_set_option never changes a call half way; "log_n" and "half_pipeline" can also be
+// fixed per needle handle (am_needle_set_option), which wins over the default.
+static std::atomic<long long> g_opt_log_n{0};            // 0 = auto
+static std::atomic<long long> g_opt_pairs_per_group{64};
+static std::atomic<long long> g_opt_profile_mask{-1};    // bit i = bracket kernel class i with events while profiling is on
+static std::atomic<long long> g_opt_half{0};             // 1 = half-precision storage of the work matrix (config 5)
+static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
+static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
+static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
+struct Opts {
+    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense;
+};
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
+// needles longer than this run on N = 2^22 (measured crossover, tools/needle_sweep.py)
+static const long long kWideFromSamples = 7 * (1ll << 16);
 
 // ---------------------------------------------------------------------------
-static long long g_opt_vmm = 0;   // experiment: back the work matrix with hipMemCreate chunks (see DevBuf)
-
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    // EXPERIMENT (option "vmm_work"): virtual-memory-management allocation, one physical
-    // handle per `chunk` bytes, to see whether the physical fragment size behind the work
-    // matrix explains the two speeds K1/K3 show from process to process.
-    bool vmm = false;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    size_t vmm_chunk = 0;
-    int ensure_vmm(size_t bytes, int device) {
-        release();
-        hipMemAllocationProp prop{};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = device;
-        size_t gran = 0;
-        AM_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-        const size_t chunk = std::max<size_t>(gran, (size_t)g_opt_vmm << 20);
-        const size_t total = (bytes + chunk - 1) / chunk * chunk;
-        AM_HIP(hipMemAddressReserve(&p, total, chunk, nullptr, 0));
-        for (size_t off = 0; off < total; off += chunk) {
-            hipMemGenericAllocationHandle_t hnd;
-            AM_HIP(hipMemCreate(&hnd, chunk, &prop, 0));
-            handles.push_back(hnd);
-            AM_HIP(hipMemMap(static_cast<char*>(p) + off, chunk, 0, hnd, 0));
-        }
-        hipMemAccessDesc acc{};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        AM_HIP(hipMemSetAccess(p, total, &acc, 1));
-        vmm = true; vmm_chunk = chunk; cap = total;
-        return AM_OK;
-    }
-    int ensure(size_t bytes, int vmm_device = -1) {
+    int ensure(size_t bytes) {
         if (bytes <= cap) return AM_OK;
-        if (vmm_device >= 0 && g_opt_vmm > 0) return ensure_vmm(bytes + bytes / 8, vmm_device);
         release();
         size_t want = bytes + bytes / 8;
         hipError_t e = hipMalloc(&p, want);
@@ -109,16 +97,8 @@ struct DevBuf {
         return AM_OK;
     }
     void release() {
-        if (p && vmm) {
-            (void)hipDeviceSynchronize();
-            (void)hipMemUnmap(p, cap);
-            for (auto hnd : handles) (void)hipMemRelease(hnd);
-            (void)hipMemAddressFree(p, cap);
-            handles.clear();
-        } else if (p) {
-            (void)hipFree(p);
-        }
-        p = nullptr; cap = 0; vmm = false;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
     }
 };
 struct HostBuf {
@@ -147,11 +127,10 @@ enum { KN_K1 = 0, KN_K2, KN_K3, KN_STATS, KN_PEAKS, KN_OTHER, KN_COUNT };
 struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;           // second lane of the two-lane block pipeline
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    hipStream_t stream2 = nullptr;           // peak pick of haystack k beside the transforms of k+1 (batches)
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum;
+    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur;
     // second set of the score-side buffers: in a batch the peak pick of haystack k runs on
     // stream2 beside the transforms of haystack k+1, which then need their own set
     DevBuf scores_b, stats_b, stats32_b, wflags_b, peaks_b;
@@ -161,6 +140,7 @@ struct Ctx {
     // kernel writes directly (a few KB per haystack): no device-to-host copy
     // sits between the last kernel and the host's wake-up.
     HostBuf hdr;
+    HostBuf spill;   // spill arena of the single-chunk passes (same kind of memory)
     // the chunk list currently resident in `segs` (re-uploaded only when it changes)
     std::vector<Segment> segs_resident;
     // profiling
@@ -189,12 +169,10 @@ static int get_ctx(int device, Ctx** out) {
     Ctx* c = new Ctx();
     c->device = device;
     c->hdr.flags = hipHostMallocMapped | hipHostMallocCoherent;
+    c->spill.flags = hipHostMallocMapped | hipHostMallocCoherent;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
     (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming);
     for (int i = 0; i < 2; ++i) {
         (void)hipEventCreateWithFlags(&c->ev_k3[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_pick[i], hipEventDisableTiming);
@@ -215,7 +193,7 @@ struct ProfScope {
     Ctx* c; int name; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
     bool on;
     ProfScope(Ctx* c_, int name_, hipStream_t st_ = nullptr) : c(c_), name(name_), st(st_ ? st_ : c_->stream) {
-        on = c->prof && ((g_opt_profile_mask >> name) & 1);
+        on = c->prof && ((g_opt_profile_mask.load(std::memory_order_relaxed) >> name) & 1);
         if (on) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
@@ -296,38 +274,47 @@ struct am_needle {
     size_t n = 0;
     float inv_autocorr = 0.f;
     std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
-    // lowest chunk minimum of the scaled scores seen so far (per scale mode);
+    // lowest chunk minimum of the scores seen so far (index 0: unscaled, 1: AM_SCALE_LIB);
     // drives the raw-score write threshold of the fused scan
     bool have_min[2] = {false, false};
     float min_seg_min[2] = {0.f, 0.f};
+    // per-handle overrides of the process-wide option defaults (-1 = follow the default)
+    long long opt_log_n = -1, opt_half = -1;
 };
 
 namespace am {
 
-static int pick_log_n(size_t s, long long out_count, int* logN_out) {
+static Opts snapshot_opts(const am_needle* h) {
+    Opts o;
+    o.log_n = (h && h->opt_log_n >= 0) ? h->opt_log_n : g_opt_log_n.load(std::memory_order_relaxed);
+    o.half = (h && h->opt_half >= 0) ? h->opt_half : g_opt_half.load(std::memory_order_relaxed);
+    o.pairs_per_group = g_opt_pairs_per_group.load(std::memory_order_relaxed);
+    o.batch_overlap = g_opt_batch_overlap.load(std::memory_order_relaxed);
+    o.needle_group = g_opt_needle_group.load(std::memory_order_relaxed);
+    o.dense = g_opt_dense.load(std::memory_order_relaxed);
+    return o;
+}
+
+static int pick_log_n(size_t s, long long out_count, const Opts& o, int* logN_out) {
     // smallest transform that can hold the needle at all
     int min_log = kLogNMin;
     while (min_log <= kLogNMax && ((size_t)1 << min_log) < s + 1) ++min_log;
     if (min_log > kLogNMax) return fail(AM_ERR_INVALID_ARG, "needle too long for the largest transform (2^23)");
-    if (g_opt_log_n > 0) {
-        int l = (int)g_opt_log_n;
+    if (o.log_n > 0) {
+        int l = (int)o.log_n;
         if (l < min_log) l = min_log;
         if (l > kLogNMax) l = kLogNMax;
         *logN_out = l;
         return AM_OK;
     }
     const long long span = out_count + (long long)s - 1;
-    // The register-resident kernels exist for N = 2^21 only and are several times
-    // faster per point than the generic ones, so every problem that is not small
-    // runs on N = 2^21 as long as at least a quarter of each block is new output
-    // (needles up to ~1.5 M samples); short needles simply get a longer hop.
+    // The register-resident kernels exist for N = 2^21 and 2^22 only and are several times
+    // faster per point than the generic ones, so every problem that is not small runs on
+    // them; short needles simply get a longer hop.
     if (span > (1ll << 19)) {
-        // N = 2^21 (256 x 8192) while at least 3/4 of a block is new output; N = 2^22
-        // (256 x 2 x 8192, about 8 % dearer per point) for longer needles, up to 3 M
-        // samples; beyond that the generic kernels at N = 2^23
-        // measured crossover (tools/needle_sweep.py): 2^22 wins from about 10.5 s of 44.1 kHz audio
-        // (the half-precision work matrix exists on the 2^21 plan only: keep it there up to 2^19 samples)
-        if ((long long)s <= (g_opt_half ? (1ll << 19) : 7 * (1ll << 16))) { *logN_out = 21; return AM_OK; }
+        // measured crossover (tools/needle_sweep.py); the half-precision
+        // work matrix exists on the 2^21 plan only: keep it there up to 2^19 samples
+        if ((long long)s <= (o.half ? (1ll << 19) : kWideFromSamples)) { *logN_out = 21; return AM_OK; }
         if ((long long)s <= (1ll << 22) - (1ll << 20)) { *logN_out = 22; return AM_OK; }
     }
     int pref = min_log;
@@ -345,8 +332,7 @@ static int pick_log_n(size_t s, long long out_count, int* logN_out) {
 
 static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
     Ctx* c = h->ctx;
-    // the two K2 forms keep the spectrum in different (register-order) layouts
-    const int key = pl->dev.logN * 4 + (plan_k2_is_r16(pl->dev) ? 1 + g_k2_variant : 0);
+    const int key = pl->dev.logN;
     auto it = h->spectra.find(key);
     if (it != h->spectra.end()) { *out = it->second; return AM_OK; }
     const size_t N = (size_t)1 << pl->dev.logN;
@@ -371,35 +357,63 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
 }
 
 // The overlap-save engine: scores[j] = factor * sum_n X[j + n - lead] needle[n]
-// When want_stats is set and the plan supports it, K3 also writes the level-0
-// (min,max) summary into c->stats32 and *have_stats becomes true.
+// When a ScanRequest is given and the plan supports it, K3 also writes the level-0
+// (min,max) summary into the chosen set's stats32 and `fused` becomes true.
 struct ScanRequest {
     float theta;             // in: raw-score write threshold
     long long seg_c, seg_d;  // in: chunk geometry (scores i*seg_c .. i*seg_c + seg_d)
     int set;                 // in: which set of score-side buffers (0, or 1 in an overlapped batch)
     hipEvent_t before_k3;    // in: K3 must not overwrite that set before this event (or null)
+    // in: restrict the launch to the blocks that produce scores [range_a, range_b) (range_b = 0:
+    // everything).  Used to redo single chunks with theta = -inf in place.
+    long long range_a, range_b;
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
-static int run_correlation(am_needle* h, const void* d_src, long long src_len, long long lead,
+struct Geometry {
+    int logN;
+    long long N, hop, nblocks, npairs;
+};
+static int plan_geometry(size_t s, long long out_count, const Opts& o, Geometry* g) {
+    int rc = pick_log_n(s, out_count, o, &g->logN);
+    if (rc) return rc;
+    g->N = 1ll << g->logN;
+    g->hop = g->N - (long long)s + 1;
+    if (g->hop >= 8 * kTile) g->hop = (g->hop / kTile) * kTile;
+    g->nblocks = (out_count + g->hop - 1) / g->hop;
+    g->npairs = (g->nblocks + 1) / 2;
+    return AM_OK;
+}
+static bool use_half(const Opts& o, const PlanDev& pl) { return o.half && plan_is_r16(pl) && !pl.wide; }
+
+static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
                            ScanRequest* scan_req = nullptr, int src_kind = 0) {
     Ctx* c = h->ctx;
-    int logN = 0;
-    int rc = pick_log_n(h->n, out_count, &logN);
+    if (h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0) {
+        // tiny needle: direct summation, every score written, no fused scan
+        if (scan_req) {
+            scan_req->fused = false;
+            scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
+        }
+        Job job{};
+        job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
+        job.dst = d_dst; job.out_count = out_count;
+        ProfScope ps(c, KN_OTHER);
+        AM_HIP(launch_direct(c->stream, job, h->d_needle, (int)h->n, factor));
+        return AM_OK;
+    }
+    Geometry g{};
+    int rc = plan_geometry(h->n, out_count, o, &g);
     if (rc) return rc;
     const Plan* pl = nullptr;
-    if ((rc = get_plan(c, logN, &pl))) return rc;
+    if ((rc = get_plan(c, g.logN, &pl))) return rc;
     const float2* hc = nullptr;
     if ((rc = needle_spectrum(h, pl, &hc))) return rc;
-    const long long N = 1ll << logN;
-    long long hop = N - (long long)h->n + 1;
-    if (hop >= 8 * kTile) hop = (hop / kTile) * kTile;
-    const long long nblocks = (out_count + hop - 1) / hop;
-    const long long npairs = (nblocks + 1) / 2;
-    long long ppg = std::max<long long>(1, g_opt_pairs_per_group);
+    const long long N = g.N, hop = g.hop, nblocks = g.nblocks, npairs = g.npairs;
+    long long ppg = std::max<long long>(1, o.pairs_per_group);
     if (ppg > npairs) ppg = npairs;
-    if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2), c->device))) return rc;
+    if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
@@ -421,50 +435,27 @@ static int run_correlation(am_needle* h, const void* d_src, long long src_len, l
     }
     // half-precision storage of the work matrix: K2 normalises by the needle
     // energy (times a fixed gain) so that stored values sit mid-range in f16
-    const bool half = g_opt_half && plan_is_r16(pl->dev) && !pl->dev.wide && g_k2_variant == 0;
+    const bool half = use_half(o, pl->dev);
     const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
     const float k3scale = half ? factor / hscale : factor;
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
-    const bool two_lanes = g_opt_lanes == 2 && c->stream2 && c->ev_a && c->ev_b && c->ev_c && npairs >= 8 && ppg >= npairs;
-    if (!two_lanes) {
-        for (long long first = 0; first < npairs; first += ppg) {
-            const int np = (int)std::min(ppg, npairs - first);
-            job.first_pair = (int)first;
-            { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
-            { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
-            if (first == 0 && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
-            { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
-        }
-        return AM_OK;
+    long long pair_lo = 0, pair_hi = npairs;
+    if (scan_req && scan_req->range_b > scan_req->range_a) {
+        pair_lo = (scan_req->range_a / hop) / 2;
+        pair_hi = std::min(npairs, ((scan_req->range_b - 1) / hop) / 2 + 1);
     }
-    // Two-lane pipeline: the pairs are cut into four groups that alternate between
-    // two streams, the second lane one kernel behind the first, so that a
-    // bandwidth-heavy kernel of one group runs beside a latency/VALU-heavy kernel
-    // of the other.  Groups write disjoint parts of the score arrays; each lane has
-    // its own half of the work matrix (the whole matrix was sized for all pairs).
-    const long long gsz = (npairs + 3) / 4;
-    hipStream_t lane[2] = {c->stream, c->stream2};
-    // each lane owns gsz pair slots of the work matrix; groups g and g+2 reuse them in stream order
-    float2* wk[2] = {(float2*)c->work.p, (float2*)c->work.p + (size_t)gsz * (size_t)N};
-    AM_HIP(hipEventRecord(c->ev_a, c->stream));            // everything queued before this call
-    AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_a, 0));
-    int g = 0;
-    for (long long first = 0; first < npairs; first += gsz, ++g) {
-        const int ln = g & 1;
-        const int np = (int)std::min(gsz, npairs - first);
+    bool waited = false;
+    for (long long first = pair_lo; first < pair_hi; first += ppg) {
+        const int np = (int)std::min(ppg, pair_hi - first);
         job.first_pair = (int)first;
-        { ProfScope ps(c, KN_K1, lane[ln]); AM_HIP(launch_k1(lane[ln], job, np, wk[ln], pl->dev, half)); }
-        if (g == 0) {                                       // stagger: lane 1 starts after lane 0's first K1
-            AM_HIP(hipEventRecord(c->ev_b, lane[0]));
-            AM_HIP(hipStreamWaitEvent(lane[1], c->ev_b, 0));
-        }
-        { ProfScope ps(c, KN_K2, lane[ln]); AM_HIP(launch_k2(lane[ln], np, wk[ln], hc, pl->dev, nullptr, half, hscale)); }
-        { ProfScope ps(c, KN_K3, lane[ln]); AM_HIP(launch_k3(lane[ln], job, np, wk[ln], pl->dev, k3scale, scan, half)); }
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
+        if (!waited && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
+        waited = true;
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
     }
-    AM_HIP(hipEventRecord(c->ev_c, c->stream2));           // join: the main stream continues after both lanes
-    AM_HIP(hipStreamWaitEvent(c->stream, c->ev_c, 0));
     return AM_OK;
 }
 
@@ -528,13 +519,28 @@ static int upload_segments(Ctx* c, const std::vector<Segment>& segs) {
     return AM_OK;
 }
 
+// The result area of one call, in coherent pinned host memory that the peak kernel
+// writes directly: `nhdr` per-chunk headers followed by a spill arena for the peak
+// lists of chunks with more than kInlinePeaks peaks (a bump allocator in the
+// kernel; its cursor lives in device memory and is zeroed per call).
+static int prepare_results(Ctx* c, size_t nhdr, size_t arena_entries, PeakArena* arena) {
+    const size_t hdr_bytes = (sizeof(SegHeader) * nhdr + 63) / 64 * 64;
+    int rc;
+    if ((rc = c->hdr.ensure(hdr_bytes + sizeof(am_peak) * arena_entries))) return rc;
+    if ((rc = c->arena_cur.ensure(sizeof(unsigned)))) return rc;
+    AM_HIP(hipMemsetAsync(c->arena_cur.p, 0, sizeof(unsigned), c->stream));
+    arena->base = reinterpret_cast<am_peak*>(static_cast<char*>(c->hdr.p) + hdr_bytes);
+    arena->cursor = static_cast<unsigned*>(c->arena_cur.p);
+    arena->cap = (unsigned)arena_entries;
+    return AM_OK;
+}
+
 // Launches find_peaks (audio_matcher.rs:221-230) for `nsegs` segments of a
-// resident score array; segment descriptors and result headers live at
-// [seg_off, seg_off + nsegs) of the context's segment / header buffers.
+// resident score array; segment descriptors live at [seg_off, seg_off + nsegs) of the
+// context's segment buffer, result headers at [hdr_off, hdr_off + nsegs).
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
-                       float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off = -1,
-                       hipStream_t st = nullptr) {
-    if (hdr_off < 0) hdr_off = seg_off;
+                       float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off,
+                       const PeakArena& arena, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
     const int set = scan ? scan->set : 0;
     DevBuf& bstats = set ? c->stats_b : c->stats;
@@ -554,21 +560,23 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         ProfScope ps(c, KN_PEAKS, st);
         AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp));
+                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena));
     }
     return AM_OK;
 }
 
 // windows of common::chunked(chunk + overlap, hop = chunk) (audio_matcher.rs:104)
 // as slices of the global score array; a window shorter than the needle has
-// no valid lag and is skipped.
-static void make_segments(size_t len, size_t s, const am_match_params* p, std::vector<Segment>& segs) {
+// no valid lag and is skipped.  `widths` (optional) receives within.len() of each window.
+static void make_segments(size_t len, size_t s, const am_match_params* p, std::vector<Segment>& segs,
+                          std::vector<size_t>* widths = nullptr) {
     const unsigned long long window = p->chunk + p->overlap;
     for (unsigned long long off = 0; off < len; off += p->chunk) {
         const unsigned long long w = std::min<unsigned long long>(window, len - off);
         if (w < s) continue;
         Segment sg; sg.a = (long long)off; sg.b = (long long)(off + w - s + 1);
         segs.push_back(sg);
+        if (widths) widths->push_back((size_t)w);
     }
 }
 
@@ -590,80 +598,132 @@ static int merge_peaks(std::vector<am_peak>& all, const am_match_params* p, am_p
     return AM_OK;
 }
 
+// Appends the peaks of header `hd` (inline, or spilled to the arena) to `all`.
+static void append_header_peaks(const SegHeader& hd, const PeakArena& arena, std::vector<am_peak>& all) {
+    if (hd.n <= kInlinePeaks) {
+        for (int j = 0; j < hd.n; ++j) all.push_back(hd.first[j]);
+    } else {
+        const am_peak* src = arena.base + hd.arena_off;
+        all.insert(all.end(), src, src + hd.n);
+    }
+}
+
+static inline const void* advance_src(const void* src, size_t elements) {
+    // one f32 mono sample and one interleaved i16 stereo frame are both 4 bytes
+    return static_cast<const char*>(src) + 4 * elements;
+}
+
 // calc_chunks (audio_matcher.rs:88-141) over a batch of resident haystacks =
 // the per-file loop of matcher::run (matcher/mod.rs:42-87).  Everything is
-// queued on the context's stream without host synchronisation; one small
-// device-to-host copy of the per-chunk headers ends the batch.
+// queued on the context's stream without host synchronisation; the per-chunk
+// result headers land in pinned host memory, so no copy ends the batch.
+//
+// scale == AM_SCALE_MY (MyConvolve's semantics, audio_matcher.rs:442-448): the factor
+// 1 / (sum(needle^2) * within.len()) depends on the window, so the windows of full
+// length share the main pass and every shorter window at the end of a haystack is
+// correlated on its own with its own factor.
 static int match_many(am_needle* h, const void* const* d_hays, const size_t* lens, size_t n_hay,
-                      const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0) {
+                      const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0,
+                      size_t index_base = 0, size_t index_stride = 1) {
     Ctx* c = h->ctx;
+    const Opts o = snapshot_opts(h);
+    const Hooks hooks = snapshot_hooks();
+    // local haystack k is item G(k) of the caller's batch: out, n_out and the progress
+    // callbacks use that index (pool submit threads pass their shard: base + k * stride)
+    auto G = [&](size_t k) { return index_base + k * index_stride; };
     const size_t s = h->n;
     if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
-    if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
-        return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB (AM_SCALE_MY depends on the window length)");
-    const float factor = scale_factor(h, p->scale, 1);
+    if (p->scale < AM_SCALE_NONE || p->scale > AM_SCALE_MY) return fail(AM_ERR_INVALID_ARG, "bad scale");
+    const bool my = p->scale == AM_SCALE_MY;
+    const size_t window = (size_t)(p->chunk + p->overlap);
+    const float factor = scale_factor(h, p->scale, window);
     // Raw scores are written only where some score >= theta.  theta sits half a
     // prominence above the lowest chunk minimum seen with this needle; the first
     // call (no history) writes everything.  The peak kernel certifies per chunk
-    // that theta was low enough; a failed certificate redoes that haystack.
+    // that theta was low enough; a chunk that fails is redone with theta = -inf.
     const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
+    const bool sparse_ok = !my && !o.dense && h->have_min[sm] && p->min_prominence > 0.f;
     ScanRequest scan{};
-    scan.theta = (h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+    scan.theta = sparse_ok ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
     scan.seg_c = (long long)p->chunk;
     scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
-    std::vector<Segment> segs;
-    std::vector<int> seg_off(n_hay + 1, 0);
+    // main-pass segments of every haystack, back to back; MyConvolve scaling keeps the
+    // shorter windows at the end of a haystack for the second pass
+    std::vector<Segment> segs, tail_segs;
+    std::vector<size_t> widths, tail_w;
+    std::vector<int> seg_off(n_hay + 1, 0), tail_off(n_hay + 1, 0), n_chunks(n_hay, 0);
     size_t max_scores = 0, max_segs = 0;
     for (size_t k = 0; k < n_hay; ++k) {
-        n_out[k] = 0;
+        n_out[G(k)] = 0;
         seg_off[k] = (int)segs.size();
+        tail_off[k] = (int)tail_segs.size();
         if (d_hays[k] && lens[k] >= s) {
-            make_segments(lens[k], s, p, segs);
+            std::vector<Segment> one; std::vector<size_t> w1;
+            make_segments(lens[k], s, p, one, &w1);
+            n_chunks[k] = (int)one.size();
+            for (size_t i = 0; i < one.size(); ++i) {
+                if (my && w1[i] != window) { tail_segs.push_back(one[i]); tail_w.push_back(w1[i]); }
+                else { segs.push_back(one[i]); widths.push_back(w1[i]); }
+            }
             max_scores = std::max(max_scores, lens[k] - s + 1);
         }
-        max_segs = std::max(max_segs, segs.size() - (size_t)seg_off[k]);
+        max_segs = std::max(max_segs, std::max(segs.size() - (size_t)seg_off[k], (size_t)1));
     }
     seg_off[n_hay] = (int)segs.size();
+    tail_off[n_hay] = (int)tail_segs.size();
     const size_t nsegs = segs.size();
-    if (nsegs == 0) return AM_OK;
+    if (nsegs == 0 && tail_segs.empty()) return AM_OK;
     if (max_segs > (size_t)1 << 18 || nsegs > (size_t)1 << 24)
         return fail(AM_ERR_INVALID_ARG, "chunk size too small for this haystack (more than 2^18 chunks)");
     int rc;
-    const size_t hdr_bytes = sizeof(SegHeader) * nsegs;
     // In a batch the peak pick of haystack k (small, latency-bound kernels) runs on a second
     // stream beside the transforms of haystack k+1; the score-side buffers alternate between
     // two sets and K3 waits for the pick that last read the set it is about to overwrite.
     size_t n_active = 0;
     for (size_t k = 0; k < n_hay; ++k) n_active += seg_off[k + 1] > seg_off[k];
-    const bool overlap = g_opt_batch_overlap && n_active > 1 && g_opt_lanes != 2 && c->stream2 &&
+    const bool overlap = o.batch_overlap && n_active > 1 && c->stream2 &&
                          c->ev_k3[0] && c->ev_k3[1] && c->ev_pick[0] && c->ev_pick[1];
     if ((rc = c->scores.ensure(max_scores * sizeof(float)))) return rc;
-    if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     if (overlap) {
         if ((rc = c->scores_b.ensure(max_scores * sizeof(float)))) return rc;
         if ((rc = c->peaks_b.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     }
-    if ((rc = upload_segments(c, segs))) return rc;
+    // one spare header behind the main ones serves the single-chunk passes below; the arena
+    // holds every list of one haystack in the worst case plus a few entries per chunk
+    PeakArena arena{};
+    if ((rc = prepare_results(c, nsegs + 1, max_segs * AM_MAX_PEAKS_PER_CHUNK + nsegs * 8, &arena))) return rc;
+    // the resident chunk list: the main-pass chunks, then one local slice [0, count) per
+    // second-pass window (those are correlated on their own, see below)
+    std::vector<Segment> resident = segs;
+    for (const Segment& sg : tail_segs) { Segment local; local.a = 0; local.b = sg.b - sg.a; resident.push_back(local); }
+    if ((rc = upload_segments(c, resident))) return rc;
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
+    auto chunk_events = [&](size_t k, int stage) {
+        if (hooks.chunk_fn)
+            for (int i = 0; i < n_chunks[k]; ++i)
+                hooks.chunk_fn(hooks.chunk_user, G(k), (size_t)i, (size_t)n_chunks[k], stage);
+    };
     size_t seq = 0;
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
+        if (n_chunks[k] == 0) continue;
+        if (hooks.fn) hooks.fn(hooks.user, G(k), 0, (size_t)n_chunks[k]);
+        chunk_events(k, 0);
         if (ns == 0) continue;
-        if (g_progress_fn) g_progress_fn(g_progress_user, k, 0, (size_t)ns);
         const long long out_count = (long long)(lens[k] - s + 1);
         const int set = overlap ? (int)(seq & 1) : 0;
         float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
         scan.set = set;
         scan.before_k3 = (overlap && seq >= 2) ? c->ev_pick[set] : nullptr;
-        if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, d_scores, out_count, factor,
+        if ((rc = run_correlation(h, o, d_hays[k], (long long)lens[k], 0, d_scores, out_count, factor,
                                   &scan, src_kind))) return rc;
         if (overlap) {
             AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
             AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
         }
         if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence,
-                              (long long)p->min_distance, &scan, -1, overlap ? c->stream2 : c->stream))) return rc;
+                              (long long)p->min_distance, &scan, seg_off[k], arena, overlap ? c->stream2 : c->stream))) return rc;
         if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
         ++seq;
     }
@@ -673,44 +733,69 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     scan.before_k3 = nullptr;
     int worst = AM_OK;
     std::vector<am_peak> all;
+    const int spare_hdr = (int)nsegs;
     for (size_t k = 0; k < n_hay; ++k) {
         const int s0 = seg_off[k], s1 = seg_off[k + 1];
-        if (s1 == s0) continue;
-        bool big = false;
+        if (n_chunks[k] == 0) continue;
+        const long long out_count = (long long)(lens[k] - s + 1);
         for (int i = s0; i < s1; ++i) {
             if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-            if (h_hdr[i].n > kInlinePeaks || (h_hdr[i].overflow & 2)) big = true;
-            if (!h->have_min[sm] || h_hdr[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = h_hdr[i].seg_min; h->have_min[sm] = true; }
+            if (!my && (!h->have_min[sm] || h_hdr[i].seg_min < h->min_seg_min[sm])) { h->min_seg_min[sm] = h_hdr[i].seg_min; h->have_min[sm] = true; }
         }
         all.clear();
-        if (!big) {
-            // collect in window order (audio_matcher.rs:132-133)
-            for (int i = s0; i < s1; ++i)
-                for (int j = 0; j < h_hdr[i].n; ++j) all.push_back(h_hdr[i].first[j]);
-        } else {
-            // rare: a chunk with more peaks than a header holds (its full list was
-            // overwritten by later haystacks) or a chunk whose minimum was below
-            // what theta assumed: redo this haystack on its own, writing every score
-            const long long out_count = (long long)(lens[k] - s + 1);
+        // collect in window order (audio_matcher.rs:132-133)
+        for (int i = s0; i < s1; ++i) {
+            if (!(h_hdr[i].overflow & 6)) { append_header_peaks(h_hdr[i], arena, all); continue; }
+            // Rare: theta was too high for this chunk (its minimum lies further below the lowest
+            // minimum seen so far than half a prominence), or its list found no room in the spill
+            // arena.  Redo the blocks that produce this chunk's scores with theta = -inf, in place
+            // in set 0 (same block layout, hence bit-identical scores), and pick the chunk again
+            // with a spill arena of its own.
             ScanRequest full = scan;
             full.theta = -FLT_MAX;
-            if ((rc = run_correlation(h, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
+            full.range_a = segs[i].a; full.range_b = segs[i].b;
+            PeakArena own{};
+            if ((rc = c->spill.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+            AM_HIP(hipMemsetAsync(c->arena_cur.p, 0, sizeof(unsigned), c->stream));
+            own.base = static_cast<am_peak*>(c->spill.p); own.cursor = static_cast<unsigned*>(c->arena_cur.p);
+            own.cap = AM_MAX_PEAKS_PER_CHUNK;
+            if ((rc = run_correlation(h, o, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
                                       &full, src_kind))) return rc;
-            if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, s0, s1 - s0, p->min_prominence,
-                                  (long long)p->min_distance, &full))) return rc;
+            if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, i, 1, p->min_prominence,
+                                  (long long)p->min_distance, &full, spare_hdr, own))) return rc;
             AM_HIP(hipStreamSynchronize(c->stream));
-            for (int i = s0; i < s1; ++i) {
-                if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-                const int cnt = h_hdr[i].n;
-                if (cnt <= 0) continue;
-                const size_t old = all.size();
-                all.resize(old + cnt);
-                AM_HIP(copy_on_stream(c, all.data() + old, (am_peak*)c->peaks.p + (size_t)(i - s0) * AM_MAX_PEAKS_PER_CHUNK,
-                                 sizeof(am_peak) * cnt, hipMemcpyDeviceToHost));
-            }
+            const SegHeader& hd = h_hdr[spare_hdr];
+            if (hd.overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+            if (!my && hd.seg_min < h->min_seg_min[sm]) h->min_seg_min[sm] = hd.seg_min;
+            append_header_peaks(hd, own, all);
         }
-        rc = merge_peaks(all, p, out ? out + k * cap_per_hay : nullptr, cap_per_hay, &n_out[k]);
-        if (g_progress_fn) g_progress_fn(g_progress_user, k, 1, (size_t)(s1 - s0));
+        // second pass (MyConvolve scaling only): the shorter windows at the end of the haystack
+        for (int i = tail_off[k]; i < tail_off[k + 1]; ++i) {
+            const Segment sg = tail_segs[i];
+            const long long cnt = sg.b - sg.a;
+            ScanRequest one{};
+            one.theta = -FLT_MAX;
+            one.seg_c = 0; one.seg_d = 0;
+            PeakArena own{};
+            if ((rc = c->spill.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+            AM_HIP(hipMemsetAsync(c->arena_cur.p, 0, sizeof(unsigned), c->stream));
+            own.base = static_cast<am_peak*>(c->spill.p); own.cursor = static_cast<unsigned*>(c->arena_cur.p);
+            own.cap = AM_MAX_PEAKS_PER_CHUNK;
+            if ((rc = c->scores.ensure((size_t)cnt * sizeof(float)))) return rc;
+            if ((rc = run_correlation(h, o, advance_src(d_hays[k], (size_t)sg.a), (long long)tail_w[i], 0, (float*)c->scores.p, cnt,
+                                      scale_factor(h, p->scale, tail_w[i]), &one, src_kind))) return rc;
+            if ((rc = launch_pick(c, (const float*)c->scores.p, cnt, (int)nsegs + i, 1, p->min_prominence,
+                                  (long long)p->min_distance, &one, spare_hdr, own))) return rc;
+            AM_HIP(hipStreamSynchronize(c->stream));
+            const SegHeader& hd = h_hdr[spare_hdr];
+            if (hd.overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+            const size_t old = all.size();
+            append_header_peaks(hd, own, all);
+            for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }   // audio_matcher.rs:126
+        }
+        rc = merge_peaks(all, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
+        chunk_events(k, 1);
+        if (hooks.fn) hooks.fn(hooks.user, G(k), 1, (size_t)n_chunks[k]);
         if (rc == AM_ERR_CAPACITY) worst = rc;
         else if (rc) return rc;
     }
@@ -719,14 +804,15 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
 
 
 // BASELINE config 4: several needles against one resident haystack.  The
-// haystack's forward column pass (K1) runs once; every needle then gets its own
-// K2 (row transforms + multiply with that needle's spectrum, written to a second
-// work matrix), K3 (fused scan) and peak pick.  Needles must share one length so
-// that they share the block layout.
+// haystack's forward column pass (K1) runs once; needles are then taken in groups
+// that share the forward row transforms of K2 (k2_rows_r16_group), each needle
+// with its own inverse rows, K3 (fused scan) and peak pick.  Needles must share
+// one length so that they share the block layout.
 static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, size_t len, int src_kind,
                        const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out) {
     am_needle* h0 = needles[0];
     Ctx* c = h0->ctx;
+    const Opts o = snapshot_opts(h0);
     const size_t s = h0->n;
     for (size_t k = 0; k < nn; ++k) {
         n_out[k] = 0;
@@ -735,7 +821,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     }
     if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
     if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
-        return fail(AM_ERR_INVALID_ARG, "am_match supports AM_SCALE_NONE and AM_SCALE_LIB");
+        return fail(AM_ERR_INVALID_ARG, "am_match_multi supports AM_SCALE_NONE and AM_SCALE_LIB");
     if (len < s) return AM_OK;
     const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
     std::vector<Segment> segs;
@@ -743,29 +829,26 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     const int nsegs = (int)segs.size();
     if (nsegs == 0) return AM_OK;
     const long long out_count = (long long)(len - s + 1);
-    int rc, logN = 0;
-    if ((rc = pick_log_n(s, out_count, &logN))) return rc;
+    int rc;
+    Geometry g{};
+    if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
     const Plan* pl = nullptr;
-    if ((rc = get_plan(c, logN, &pl))) return rc;
-    const long long N = 1ll << logN;
-    long long hop = N - (long long)s + 1;
-    if (hop >= 8 * kTile) hop = (hop / kTile) * kTile;
-    const long long nblocks = (out_count + hop - 1) / hop;
-    const long long npairs = (nblocks + 1) / 2;
+    if ((rc = get_plan(c, g.logN, &pl))) return rc;
+    const long long N = g.N, hop = g.hop, nblocks = g.nblocks, npairs = g.npairs;
     std::vector<const float2*> hcs(nn);
     for (size_t k = 0; k < nn; ++k)
         if ((rc = needle_spectrum(needles[k], pl, &hcs[k]))) return rc;   // may use c->work: before it is filled
     if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
-    const bool half = g_opt_half && plan_is_r16(pl->dev) && !pl->dev.wide && g_k2_variant == 0;
+    const bool half = use_half(o, pl->dev);
     // needles are taken in groups that share the forward row transforms of K2
     const size_t group = (!half && plan_k2_has_group(pl->dev))
-        ? (size_t)std::min<long long>(std::max<long long>(1, g_opt_needle_group), kMaxNeedleGroup) : 1;
+        ? (size_t)std::min<long long>(std::max<long long>(1, o.needle_group), kMaxNeedleGroup) : 1;
     const size_t matrix = (size_t)npairs * (size_t)N;   // points of one needle's work matrix
     if ((rc = c->work2.ensure(std::min(group, nn) * matrix * sizeof(float2)))) return rc;
     if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
-    const size_t hdr_bytes = sizeof(SegHeader) * nsegs * nn;
-    if ((rc = c->hdr.ensure(hdr_bytes))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * (size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    PeakArena arena{};
+    if ((rc = prepare_results(c, (size_t)nsegs * nn, (size_t)nsegs * nn * 8 + 4096, &arena))) return rc;
     if ((rc = upload_segments(c, segs))) return rc;
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     const bool fused = plan_is_r16(pl->dev) && (hop % kTile) == 0;
@@ -790,7 +873,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
             AM_HIP(launch_k2_group(c->stream, (int)npairs, (const float2*)c->work.p, grp, pl->dev));
         }
         ScanRequest scan{};
-        scan.theta = (h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+        scan.theta = (!o.dense && h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
         scan.seg_c = (long long)p->chunk;
         scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
         scan.fused = fused;
@@ -807,7 +890,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, inv_rows, pl->dev,
                                                   half ? factor / hscale : factor, cfg, half)); }
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
-                              (long long)p->min_distance, &scan, (int)(k * nsegs)))) return rc;
+                              (long long)p->min_distance, &scan, (int)(k * nsegs), arena))) return rc;
     }
     AM_HIP(hipStreamSynchronize(c->stream));
     int worst = AM_OK;
@@ -815,24 +898,30 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     for (size_t k = 0; k < nn; ++k) {
         am_needle* h = needles[k];
         const SegHeader* hd = h_hdr + k * nsegs;
-        bool big = false;
+        bool redo = false;
         for (int i = 0; i < nsegs; ++i) {
             if (hd[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-            if (hd[i].n > kInlinePeaks || (hd[i].overflow & 2)) big = true;
+            if (hd[i].overflow & 6) redo = true;
             if (!h->have_min[sm] || hd[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = hd[i].seg_min; h->have_min[sm] = true; }
         }
-        am_peak* dst = out ? out + k * cap_per_needle : nullptr;
-        if (big) {   // rare: redo this needle alone through the single-needle path (writes every score)
-            const bool keep = h->have_min[sm];
-            h->have_min[sm] = false;             // forces theta = -inf
-            rc = match_many(h, &d_hay, &len, 1, p, dst, cap_per_needle, &n_out[k], src_kind);
-            h->have_min[sm] = h->have_min[sm] || keep;
+        all.clear();
+        if (!redo)
+            for (int i = 0; i < nsegs; ++i) append_header_peaks(hd[i], arena, all);
+        if (!redo) {
+            rc = merge_peaks(all, p, out ? out + k * cap_per_needle : nullptr, cap_per_needle, &n_out[k]);
+            if (rc == AM_ERR_CAPACITY) worst = rc;
+            else if (rc) return rc;
         } else {
-            all.clear();
-            for (int i = 0; i < nsegs; ++i)
-                for (int j = 0; j < hd[i].n; ++j) all.push_back(hd[i].first[j]);
-            rc = merge_peaks(all, p, dst, cap_per_needle, &n_out[k]);
+            n_out[k] = (size_t)-1;   // marked: redone below, once the shared result area is no longer needed
         }
+    }
+    // rare: a needle with a failed certificate or a lost spill goes through the single-needle
+    // path (which redoes exactly the chunks that need it); this reuses the result area, so
+    // it runs after every other needle has been collected
+    for (size_t k = 0; k < nn; ++k) {
+        if (n_out[k] != (size_t)-1) continue;
+        n_out[k] = 0;
+        rc = match_many(needles[k], &d_hay, &len, 1, p, out ? out + k * cap_per_needle : nullptr, cap_per_needle, &n_out[k], src_kind);
         if (rc == AM_ERR_CAPACITY) worst = rc;
         else if (rc) return rc;
     }
@@ -844,15 +933,16 @@ static int find_peaks_host_array(Ctx* c, const float* d_scores, long long n, flo
                                  std::vector<am_peak>& all) {
     int rc;
     Segment sg; sg.a = 0; sg.b = n;
-    if ((rc = c->hdr.ensure(sizeof(SegHeader)))) return rc;
+    PeakArena arena{};
+    if ((rc = prepare_results(c, 1, AM_MAX_PEAKS_PER_CHUNK, &arena))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     if ((rc = upload_segments(c, std::vector<Segment>(1, sg)))) return rc;
-    if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr))) return rc;
+    if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr, 0, arena))) return rc;
     AM_HIP(hipStreamSynchronize(c->stream));
     const SegHeader hd = *static_cast<const SegHeader*>(c->hdr.p);
     if (hd.overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-    all.resize(hd.n);
-    if (hd.n > 0) AM_HIP(copy_on_stream(c, all.data(), c->peaks.p, sizeof(am_peak) * hd.n, hipMemcpyDeviceToHost));
+    all.clear();
+    append_header_peaks(hd, arena, all);
     return AM_OK;
 }
 
@@ -883,6 +973,22 @@ static int create_needle_common(Ctx* c, float* d_needle, size_t n, am_needle** o
 }  // namespace am
 
 using namespace am;
+
+// ---------------------------------------------------------------------------
+// The haystack batch over several devices (matcher/mod.rs:42-87 sharded).
+struct am_pool {
+    struct Slot {
+        int device = -1;
+        am_needle* needle = nullptr;
+        // two-slot HBM ring + copy stream of the host-buffer path
+        void* ring[2] = {nullptr, nullptr};
+        size_t ring_cap = 0;
+        hipStream_t copy_stream = nullptr;
+    };
+    std::vector<Slot> slots;
+    std::mutex mu;   // one batch at a time per pool
+};
+
 
 // ===========================================================================
 extern "C" {
@@ -981,7 +1087,8 @@ static int correlate_impl(const am_needle* hc, const float* within, size_t w, in
         d_in = (const float*)c->io_in.p;
         d_out = (float*)c->io_out.p;
     }
-    if ((rc = run_correlation(h, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
+    const Opts o = snapshot_opts(h);
+    if ((rc = run_correlation(h, o, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
     AM_HIP(hipStreamSynchronize(c->stream));
     if (!device_io) AM_HIP(copy_on_stream(c, out, d_out, len * sizeof(float), hipMemcpyDeviceToHost));
     return AM_OK;
@@ -1226,10 +1333,11 @@ int am_shutdown(void) {
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
                           &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b,
-                          &c->peaks, &c->io_in, &c->io_out, &c->sum})
+                          &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
         if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }
+        if (c->spill.p) { (void)hipHostFree(c->spill.p); c->spill.p = nullptr; c->spill.cap = 0; }
         c->segs_resident.clear();
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
         c->plans.clear();
@@ -1241,9 +1349,205 @@ int am_shutdown(void) {
     return AM_OK;
 }
 
+
+// ---- pool ---------------------------------------------------------------------
+int am_shard_plan(size_t n_items, size_t n_shards, size_t shard, size_t* first, size_t* stride, size_t* count) {
+    if (!first || !stride || !count || n_shards == 0 || shard >= n_shards) return fail(AM_ERR_INVALID_ARG, "bad shard");
+    *first = shard;
+    *stride = n_shards;
+    *count = n_items > shard ? (n_items - shard + n_shards - 1) / n_shards : 0;
+    return AM_OK;
+}
+
+int am_pool_create(const float* needle, size_t n, const int* devices, size_t n_dev, am_pool** out) {
+    if (!needle || !out || n == 0) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+    std::vector<int> devs;
+    if (devices) {
+        if (n_dev == 0) return fail(AM_ERR_INVALID_ARG, "empty device list");
+        devs.assign(devices, devices + n_dev);
+    } else {
+        int k = 0;
+        if (hipGetDeviceCount(&k) != hipSuccess || k <= 0) return fail(AM_ERR_NO_DEVICE, "no HIP device available");
+        for (int d = 0; d < k; ++d) devs.push_back(d);
+    }
+    am_pool* pool = new am_pool();
+    pool->slots.resize(devs.size());
+    for (size_t i = 0; i < devs.size(); ++i) {
+        am_pool::Slot& sl = pool->slots[i];
+        sl.device = devs[i];
+        int rc = am_needle_create(devs[i], needle, n, &sl.needle);
+        if (rc == AM_OK && hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking) != hipSuccess)
+            rc = fail(AM_ERR_HIP, "hipStreamCreate(pool copy stream)");
+        if (rc) { const std::string keep = t_err; am_pool_destroy(pool); t_err = keep; return rc; }
+    }
+    *out = pool;
+    return AM_OK;
+}
+
+void am_pool_destroy(am_pool* pool) {
+    if (!pool) return;
+    for (am_pool::Slot& sl : pool->slots) {
+        if (sl.device >= 0) (void)hipSetDevice(sl.device);
+        if (sl.copy_stream) { (void)hipStreamSynchronize(sl.copy_stream); (void)hipStreamDestroy(sl.copy_stream); }
+        for (void* r : sl.ring) if (r) (void)hipFree(r);
+        am_needle_destroy(sl.needle);
+    }
+    delete pool;
+}
+
+int am_pool_size(const am_pool* pool, size_t* n_dev) {
+    if (!pool || !n_dev) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    *n_dev = pool->slots.size();
+    return AM_OK;
+}
+
+int am_pool_slot(const am_pool* pool, size_t slot, int* device, const am_needle** needle) {
+    if (!pool || slot >= pool->slots.size()) return fail(AM_ERR_INVALID_ARG, "bad pool slot");
+    if (device) *device = pool->slots[slot].device;
+    if (needle) *needle = pool->slots[slot].needle;
+    return AM_OK;
+}
+
+namespace {
+
+// resident haystacks: the slot's shard goes through match_many as one batch
+int slot_run_device(am_pool::Slot& sl, size_t slot, size_t nslots, const float* const* d_hays, const size_t* lens, size_t n_hay,
+                    const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    size_t first, stride, count;
+    am_shard_plan(n_hay, nslots, slot, &first, &stride, &count);
+    if (count == 0) return AM_OK;
+    std::vector<const void*> ptrs(count);
+    std::vector<size_t> ln(count);
+    for (size_t i = 0; i < count; ++i) { ptrs[i] = d_hays[first + i * stride]; ln[i] = lens[first + i * stride]; }
+    am_needle* h = sl.needle;
+    int rc = check_needle(h);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    return match_many(h, ptrs.data(), ln.data(), count, p, out, cap_per_hay, n_out, 0, first, stride);
+}
+
+// host haystacks: a copier thread fills the two-slot ring one haystack ahead of the matcher
+int slot_run_host(am_pool::Slot& sl, size_t slot, size_t nslots, const float* const* hays, const size_t* lens, size_t n_hay,
+                  const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    size_t first, stride, count;
+    am_shard_plan(n_hay, nslots, slot, &first, &stride, &count);
+    if (count == 0) return AM_OK;
+    am_needle* h = sl.needle;
+    int rc = check_needle(h);   // hipSetDevice for this thread
+    if (rc) return rc;
+    size_t max_len = 0;
+    for (size_t i = 0; i < count; ++i) if (hays[first + i * stride]) max_len = std::max(max_len, lens[first + i * stride]);
+    if (max_len * sizeof(float) > sl.ring_cap) {
+        for (void*& r : sl.ring) { if (r) (void)hipFree(r); r = nullptr; }
+        sl.ring_cap = 0;
+        for (void*& r : sl.ring) {
+            hipError_t e = hipMalloc(&r, max_len * sizeof(float));
+            if (e != hipSuccess) { r = nullptr; return hip_fail(e, "hipMalloc(pool ring)"); }
+        }
+        sl.ring_cap = max_len * sizeof(float);
+    }
+    std::mutex m;
+    std::condition_variable cv;
+    bool ready[2] = {false, false};
+    hipError_t copy_err = hipSuccess;
+    bool stop = false;
+    std::thread copier([&] {
+        (void)hipSetDevice(sl.device);
+        for (size_t i = 0; i < count; ++i) {
+            const int b = (int)(i & 1);
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return !ready[b] || stop; });
+                if (stop) return;
+            }
+            const size_t k = first + i * stride;
+            hipError_t e = hipSuccess;
+            if (hays[k] && lens[k]) {
+                e = hipMemcpyAsync(sl.ring[b], hays[k], lens[k] * sizeof(float), hipMemcpyHostToDevice, sl.copy_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(sl.copy_stream);
+            }
+            std::lock_guard<std::mutex> lk(m);
+            if (e != hipSuccess) { copy_err = e; stop = true; cv.notify_all(); return; }
+            ready[b] = true;
+            cv.notify_all();
+        }
+    });
+    int worst = AM_OK;
+    for (size_t i = 0; i < count; ++i) {
+        const int b = (int)(i & 1);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return ready[b] || stop; });
+            if (stop) break;
+        }
+        const size_t k = first + i * stride;
+        const void* src = (hays[k] && lens[k]) ? sl.ring[b] : nullptr;
+        {
+            std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+            rc = match_many(h, &src, &lens[k], 1, p, out, cap_per_hay, n_out, 0, k, 1);
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            ready[b] = false;
+            if (rc != AM_OK && rc != AM_ERR_CAPACITY) stop = true;
+            cv.notify_all();
+        }
+        if (rc == AM_ERR_CAPACITY) worst = rc;
+        else if (rc) { worst = rc; break; }
+    }
+    copier.join();
+    if (copy_err != hipSuccess) return hip_fail(copy_err, "host-to-device copy (pool)");
+    return worst;
+}
+
+int pool_run(am_pool* pool, const float* const* hays, const size_t* lens, size_t n_hay, const am_match_params* p,
+             am_peak* out, size_t cap_per_hay, size_t* n_out, bool host) {
+    if (!pool || !hays || !lens || !p || !n_out || (!out && cap_per_hay)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(pool->mu);
+    const size_t nslots = pool->slots.size();
+    for (size_t k = 0; k < n_hay; ++k) n_out[k] = 0;
+    if (n_hay == 0) return AM_OK;
+    std::vector<int> rcs(nslots, AM_OK);
+    std::vector<std::string> errs(nslots);
+    std::vector<std::thread> threads;
+    for (size_t s = 0; s < nslots; ++s)
+        threads.emplace_back([&, s] {
+            rcs[s] = host ? slot_run_host(pool->slots[s], s, nslots, hays, lens, n_hay, p, out, cap_per_hay, n_out)
+                          : slot_run_device(pool->slots[s], s, nslots, hays, lens, n_hay, p, out, cap_per_hay, n_out);
+            if (rcs[s]) errs[s] = t_err;   // the error string is thread-local: hand it to the caller's thread
+        });
+    for (std::thread& th : threads) th.join();
+    int worst = AM_OK;
+    for (size_t s = 0; s < nslots; ++s) {
+        if (rcs[s] == AM_OK) continue;
+        if (worst == AM_OK || worst == AM_ERR_CAPACITY) { worst = rcs[s]; t_err = errs[s]; }
+    }
+    return worst;
+}
+
+}  // namespace
+
+int am_pool_match_batch(am_pool* pool, const float* const* haystacks, const size_t* lens, size_t n_hay,
+                        const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    return pool_run(pool, haystacks, lens, n_hay, p, out, cap_per_hay, n_out, true);
+}
+
+int am_pool_match_batch_device(am_pool* pool, const float* const* d_haystacks, const size_t* lens, size_t n_hay,
+                               const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    return pool_run(pool, d_haystacks, lens, n_hay, p, out, cap_per_hay, n_out, false);
+}
+
 int am_set_progress_callback(am_progress_fn fn, void* user) {
-    g_progress_fn = fn;
-    g_progress_user = user;
+    std::lock_guard<std::mutex> lk(g_hooks_mu);
+    g_hooks.fn = fn;
+    g_hooks.user = user;
+    return AM_OK;
+}
+
+int am_set_chunk_progress_callback(am_chunk_progress_fn fn, void* user) {
+    std::lock_guard<std::mutex> lk(g_hooks_mu);
+    g_hooks.chunk_fn = fn;
+    g_hooks.chunk_user = user;
     return AM_OK;
 }
 
@@ -1289,20 +1593,12 @@ int am_set_option(const char* key, long long value) {
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
-    if (!strcmp(key, "vmm_work")) { g_opt_vmm = value < 0 ? 0 : value; return AM_OK; }
+    if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
         if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
         g_opt_needle_group = value; return AM_OK;
     }
     if (!strcmp(key, "profile_mask")) { g_opt_profile_mask = value; return AM_OK; }
-    if (!strcmp(key, "lanes")) {
-        if (value != 1 && value != 2) return fail(AM_ERR_INVALID_ARG, "lanes must be 1 or 2");
-        g_opt_lanes = value; return AM_OK;
-    }
-    if (!strcmp(key, "k2_variant")) {
-        if (value < 0 || value > 1) return fail(AM_ERR_INVALID_ARG, "k2_variant must be 0 or 1");
-        g_k2_variant = (int)value; return AM_OK;
-    }
     if (!strcmp(key, "pairs_per_group")) {
         if (value < 1 || value > 64) return fail(AM_ERR_INVALID_ARG, "pairs_per_group out of range");
         g_opt_pairs_per_group = value; return AM_OK;
@@ -1313,13 +1609,30 @@ int am_get_option(const char* key, long long* value) {
     if (!key || !value) return fail(AM_ERR_INVALID_ARG, "null pointer");
     if (!strcmp(key, "log_n")) { *value = g_opt_log_n; return AM_OK; }
     if (!strcmp(key, "pairs_per_group")) { *value = g_opt_pairs_per_group; return AM_OK; }
-    if (!strcmp(key, "k2_variant")) { *value = g_k2_variant; return AM_OK; }
     if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
     if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
-    if (!strcmp(key, "lanes")) { *value = g_opt_lanes; return AM_OK; }
+    if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
+}
+
+int am_needle_set_option(am_needle* h, const char* key, long long value) {
+    if (!h || !h->ctx || !key) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    if (!strcmp(key, "log_n")) {
+        if (value > 0 && (value < kLogNMin || value > kLogNMax)) return fail(AM_ERR_INVALID_ARG, "log_n out of range");
+        h->opt_log_n = value < 0 ? -1 : value; return AM_OK;
+    }
+    if (!strcmp(key, "half_pipeline")) { h->opt_half = value < 0 ? -1 : (value ? 1 : 0); return AM_OK; }
+    return fail(AM_ERR_INVALID_ARG, "unknown per-handle option (log_n, half_pipeline)");
+}
+int am_needle_get_option(const am_needle* h, const char* key, long long* value) {
+    if (!h || !h->ctx || !key || !value) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    if (!strcmp(key, "log_n")) { *value = h->opt_log_n; return AM_OK; }
+    if (!strcmp(key, "half_pipeline")) { *value = h->opt_half; return AM_OK; }
+    return fail(AM_ERR_INVALID_ARG, "unknown per-handle option (log_n, half_pipeline)");
 }
 
 }  // extern "C"

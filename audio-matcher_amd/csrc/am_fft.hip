@@ -149,13 +149,47 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+// Cache policy of the work-matrix stream (aux of the raw buffer builtins on gfx940+: bit 0 =
+// sc0, bit 1 = nt, bit 4 = sc1).  The work matrix is read once and written once per kernel; the
+// needle-spectrum rows and the twiddle tables are what should stay in L2.  The defaults are the
+// measured best (tools/ntbench.hip); the macros exist for A/B builds.
+#ifndef AM_K2_LOAD_AUX
+#define AM_K2_LOAD_AUX 0
+#endif
+#ifndef AM_K2_STORE_AUX
+#define AM_K2_STORE_AUX 0
+#endif
+#ifndef AM_K1_STORE_NT
+#define AM_K1_STORE_NT 0
+#endif
+#ifndef AM_K3_LOAD_NT
+#define AM_K3_LOAD_NT 0
+#endif
+#ifndef AM_K1_LOAD_NT
+#define AM_K1_LOAD_NT 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
     return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-    return make_float2(v.x, v.y);
+// 16-byte global accesses with an optional nt bit (column passes: K1's stores, K3's loads)
+template <int NT>
+__device__ __forceinline__ float4 load_f4(const float4* p) {
+    if (NT) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *p;
+}
+template <int NT>
+__device__ __forceinline__ void store_f4(float4* p, float4 v) {
+    if (NT) {
+        f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(p));
+    } else {
+        *p = v;
+    }
 }
 // A 16-byte store reads its four data VGPRs over several cycles after issue.  hipcc (ROCm 7.2)
 // keeps the documented wait state before a VALU write of one of them only when the store has no
@@ -165,9 +199,10 @@ __device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned v
 // section 3: `buffer_store_dwordx4 v[2:5], ..., s30 offen` followed by `v_sub_f32 v4, ...`).
 // The empty-looking asm reads the data registers after the store, so nothing can overwrite them
 // before two wait states have passed.  tools/check_store_hazard.py checks the ISA for this.
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 v) {
     f32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), r, voff, soff, AUX);
     asm volatile("s_nop 1" : : "v"(o));
 }
 
@@ -214,7 +249,13 @@ __device__ __forceinline__ float load_sample(const void* __restrict__ src, long 
 // two consecutive samples from an 8-byte aligned position
 template <int KIND>
 __device__ __forceinline__ float2 load_sample2(const void* __restrict__ src, long long i) {
-    if (KIND == 0) return *reinterpret_cast<const float2*>(static_cast<const float*>(src) + i);
+    if (KIND == 0) {
+        if (AM_K1_LOAD_NT) {
+            const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(static_cast<const float*>(src) + i));
+            return make_float2(v.x, v.y);
+        }
+        return *reinterpret_cast<const float2*>(static_cast<const float*>(src) + i);
+    }
     const int2 raw = *reinterpret_cast<const int2*>(static_cast<const short2*>(src) + i);
     return make_float2(downmix_s16(__builtin_bit_cast(short2, raw.x)), downmix_s16(__builtin_bit_cast(short2, raw.y)));
 }
@@ -321,8 +362,8 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
         const size_t k1 = (size_t)(hi + 16 * bp);
-        out4[k1 * (kN2 / 2)] = make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
-                                           x1[brev<16>(bp)].x, x1[brev<16>(bp)].y);
+        store_f4<AM_K1_STORE_NT>(out4 + k1 * (kN2 / 2), make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
+                                                                    x1[brev<16>(bp)].x, x1[brev<16>(bp)].y));
     }
 }
 
@@ -406,7 +447,7 @@ __device__ __forceinline__ void k2_forward12(const K2Lane& k, __amdgpu_buffer_rs
             x0[a] = unpack_h2(v.x);
             x1[a] = unpack_h2(v.y);
         } else {
-            const float4 v = buf_load4(rrow, k.voff, a * 4096);
+            const float4 v = buf_load4<AM_K2_LOAD_AUX>(rrow, k.voff, a * 4096);
             x0[a] = make_float2(v.x, v.y);
             x1[a] = make_float2(v.z, v.w);
         }
@@ -540,7 +581,7 @@ __device__ __forceinline__ void k2_inverse(const K2Lane& k, float2 (&q)[32], flo
     }
 #pragma unroll
     for (int a = 0; a < 16; ++a)
-        buf_store4(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+        buf_store4<AM_K2_STORE_AUX>(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
                                                        x1[brev<16>(a)].x, x1[brev<16>(a)].y));
 }
 
@@ -637,135 +678,6 @@ k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsi
         k2_inverse<false>(kj, q, lds4, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
         __syncthreads();   // the last pass read rows of every wave: finish before the next needle overwrites them
     }
-}
-
-// Lane exchanges as DPP moves (VALU) rather than ds_bpermute (LDS pipe).
-template <int CTRL, int BANK_MASK = 0xF>
-__device__ __forceinline__ float dpp_mov(float old, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
-                                                                  CTRL, 0xF, BANK_MASK, false));
-}
-__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v, v); }   // quad_perm [1,0,3,2]
-__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v, v); }   // quad_perm [2,3,0,1]
-__device__ __forceinline__ float lane_xor8(float v) { return dpp_mov<0x128>(v, v); }  // row_ror:8
-__device__ __forceinline__ float lane_xor4(float v) {
-    // rotate by 4 one way for the lanes of banks 0,2 and the other way for banks 1,3
-    const float a = dpp_mov<0x12C, 0x5>(v, v);   // row_ror:12 into banks 0 and 2
-    return dpp_mov<0x124, 0xA>(a, v);            // row_ror:4  into banks 1 and 3
-}
-__device__ __forceinline__ float2 lane_xor1(float2 v) { return make_float2(lane_xor1(v.x), lane_xor1(v.y)); }
-
-// K2, 512-thread form: the same 16 x 16 x 32 factorisation with 16 points per
-// thread, so that a computing workgroup keeps two waves on every SIMD (a lone
-// wave issues VALU at half rate) and a CU holds 16 waves.  The radix-32 pass is
-// shared by lane pairs: one radix-2 stage across the pair (DPP), then a private
-// radix-16.
-__device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
-    f32x2 o; o.x = v.x; o.y = v.y;
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned, o), r, voff, soff, 0);
-}
-
-template <bool SPECTRUM>
-__global__ void __launch_bounds__(512, 4)
-k2_rows_p512(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ hc_out, PlanDev pl,
-             unsigned npairs) {
-    extern __shared__ float4 lds4[];
-    float2* lds2 = reinterpret_cast<float2*>(lds4);
-    const int t = threadIdx.x;
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned row = (seq / npairs) * 8u + xcd, slot = seq % npairs;
-    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
-    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
-    const unsigned voff = (unsigned)t * 8u;
-    const float2 wj = pl.tw2[t];
-    const float2 wc = pl.tw2[16 * (t & 31)];
-    float2 x[16];
-#pragma unroll
-    for (int a = 0; a < 16; ++a) x[a] = buf_load2(rrow, voff, a * 4096);   // element a*512 + t
-    // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = t ----
-    dif<16, false>(x);
-    twiddle_brev<16, false>(x, wj);
-#pragma unroll
-    for (int ap = 0; ap < 16; ++ap) lds2[ap * 512 + t] = x[brev<16>(ap)];   // L1[a'][j]
-    __syncthreads();
-    // ---- pass 2 over b (stride 32): a' = t >> 5, c = t & 31; twiddle W_512^(c*b') ----
-    const int ap2 = t >> 5, c2 = t & 31;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) x[b] = lds2[ap2 * 512 + b * 32 + c2];
-    dif<16, false>(x);
-    twiddle_brev<16, false>(x, wc);
-    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
-    // L2: row u = a'*16 + b' (32 points), 8-byte slot (c & 16) | ((c & 15) ^ b')
-#pragma unroll
-    for (int bp = 0; bp < 16; ++bp)
-        lds2[(ap2 * 16 + bp) * 32 + ((c2 & 16) | ((c2 & 15) ^ bp))] = x[brev<16>(bp)];
-    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
-    // ---- pass 3 over c: lane pair (u, half) holds c = half*16 + i ----
-    const int u = t >> 1, half = t & 1;
-    const float sgn = half ? -1.0f : 1.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = lds2[u * 32 + (half * 16 + (i ^ (u & 15)))];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {   // radix-2 stage across the pair: c <-> c + 16
-        const float2 p = lane_xor1(x[i]);
-        x[i] = make_float2(fmaf(sgn, x[i].x, p.x), fmaf(sgn, x[i].y, p.y));   // half 0: sum, half 1: x[c] - x[c+16]
-    }
-    if (half) {
-#pragma unroll
-        for (int i = 1; i < 16; ++i) x[i] = mul_w32<false>(x[i], i);   // W_32^c on the difference branch
-    }
-    dif<16, false>(x);   // half 0: even frequencies 2m, half 1: odd 2m+1, at x[brev(m)]
-    const size_t hoff2 = (size_t)row * kN2;
-    if (SPECTRUM) {
-        const float invN = 1.0f / (float)(1u << pl.logN);
-        const __amdgpu_buffer_rsrc_t rho = make_rsrc(hc_out + hoff2, kN2 * 8);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) buf_store2(rho, voff, i * 4096, make_float2(x[i].x * invN, -x[i].y * invN));
-        return;
-    }
-    {   // pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438)
-        const __amdgpu_buffer_rsrc_t rh = make_rsrc(hc + hoff2, kN2 * 8);
-        float2 h[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) h[i] = buf_load2(rh, voff, i * 4096);
-        float2 q[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) q[brev<16>(i)] = cmul(x[i], h[i]);   // natural frequency order m
-#pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = q[i];
-    }
-    // ---- inverse pass 3: private inverse radix-16, then the radix-2 stage across the pair ----
-    dif<16, true>(x);   // time index i at x[brev(i)] (half 0: e[i], half 1: o[i])
-    if (half) {
-#pragma unroll
-        for (int i = 1; i < 16; ++i) x[brev<16>(i)] = mul_w32<true>(x[brev<16>(i)], i);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float2 v = x[brev<16>(i)];
-        const float2 p = lane_xor1(v);
-        // half 0: e + o' -> c = i;  half 1: e - o' -> c = 16 + i
-        const float2 r = make_float2(fmaf(sgn, v.x, p.x), fmaf(sgn, v.y, p.y));
-        lds2[u * 32 + (half * 16 + (i ^ (u & 15)))] = r;   // the pair's own row: no barrier needed before
-    }
-    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
-    // ---- inverse pass 2 over b' ----
-#pragma unroll
-    for (int bp = 0; bp < 16; ++bp) x[bp] = lds2[(ap2 * 16 + bp) * 32 + ((c2 & 16) | ((c2 & 15) ^ bp))];
-    twiddle_nat<16, true>(x, wc);
-    dif<16, true>(x);
-    wave_sync_lds();   // rows 32w .. 32w+31 <-> lanes of wave w: stays inside one wavefront
-#pragma unroll
-    for (int b = 0; b < 16; ++b) lds2[ap2 * 512 + b * 32 + c2] = x[brev<16>(b)];
-    __syncthreads();
-    // ---- inverse pass 1 over a' ----
-#pragma unroll
-    for (int ap = 0; ap < 16; ++ap) x[ap] = lds2[ap * 512 + t];
-    twiddle_nat<16, true>(x, wj);
-    dif<16, true>(x);
-    const __amdgpu_buffer_rsrc_t rdst = hc_out ? make_rsrc(hc_out + row_off, kN2 * 8) : rrow;
-#pragma unroll
-    for (int a = 0; a < 16; ++a) buf_store2(rdst, voff, a * 4096, x[brev<16>(a)]);
 }
 
 // v_min3 / v_max3 without the input canonicalisation the compiler puts in front of
@@ -1022,7 +934,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
 #pragma unroll
         for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
-            const float4 v = in4[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+            const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(hi + 16 * bp) * (kN2 / 2));
             x0[bp] = make_float2(v.x, v.y);
             x1[bp] = make_float2(v.z, v.w);
         }
@@ -1262,15 +1174,39 @@ k3_cols_inv_gen(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     }
 }
 
+// ===========================================================================
+// Tiny needles (at most kDirectMaxNeedle samples): direct summation.  A transform
+// of at least 2^10 points would spend ten rounding stages on a sum of a few
+// products; summed directly the reference's own known-answer test
+// (audio_matcher.rs:490-517, integer data) comes out exact.
+// ===========================================================================
+template <int KIND>
+__global__ void __launch_bounds__(256)
+correlate_direct(Job job, const float* __restrict__ needle, int s, float out_scale) {
+    __shared__ float nd[kDirectMaxNeedle];
+    if ((int)threadIdx.x < s) nd[threadIdx.x] = needle[threadIdx.x];
+    __syncthreads();
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < job.out_count; j += (long long)gridDim.x * 256) {
+        float acc = 0.0f;
+        for (int n = 0; n < s; ++n) acc = fmaf(load_padded<KIND>(job.src, j + n - job.lead, job.src_len), nd[n], acc);
+        job.dst[j] = acc * out_scale;
+    }
+}
+
+hipError_t launch_direct(hipStream_t st, const Job& job, const float* needle, int s, float out_scale) {
+    if (s < 1 || s > kDirectMaxNeedle || job.out_count <= 0) return hipErrorInvalidValue;
+    long long blocks = (job.out_count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (job.src_kind == 1) hipLaunchKernelGGL(correlate_direct<1>, dim3((unsigned)blocks), dim3(256), 0, st, job, needle, s, out_scale);
+    else hipLaunchKernelGGL(correlate_direct<0>, dim3((unsigned)blocks), dim3(256), 0, st, job, needle, s, out_scale);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 static constexpr int kMaxLds = 160 * 1024;
 static constexpr int kR16Lds = 64 * 1024;       // K2: one 8192-point row
 static constexpr int kR16LdsK1 = 256 * 17 * 8;   // K1: one column of the pair at a time, padded rows
 static constexpr int kR16LdsK3 = 256 * 16 * 8;
-
-// 0 = 256-thread K2 (32 points per thread), 1 = 512-thread K2 (16 points per thread).
-// The needle spectrum layout differs between the two (the cache is keyed by it).
-int g_k2_variant = 0;
 
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
 // the row kernel only needs 8192-point rows; it serves any N1 (its rows are independent)
@@ -1299,8 +1235,6 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k2_rows_r16<false, true>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
     AM_SET_LDS(k2_rows_r16_group, kR16Lds)
-    AM_SET_LDS(k2_rows_p512<false>, kR16Lds)
-    AM_SET_LDS(k2_rows_p512<true>, kR16Lds)
 #undef AM_SET_LDS
     return hipSuccess;
 }
@@ -1330,10 +1264,7 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst,
                      bool half, float hscale) {
     const dim3 grid(1u << pl.logN1, npairs);
-    if (plan_k2_is_r16(pl) && g_k2_variant == 1) {
-        hipLaunchKernelGGL(k2_rows_p512<false>, dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(512), kR16Lds, st, work, hc,
-                           dst, pl, (unsigned)npairs);
-    } else if (plan_k2_is_r16(pl)) {
+    if (plan_k2_is_r16(pl)) {
         if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
         else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, hc,
@@ -1345,7 +1276,7 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
     return hipGetLastError();
 }
 
-bool plan_k2_has_group(const PlanDev& pl) { return plan_k2_is_r16(pl) && g_k2_variant == 0; }
+bool plan_k2_has_group(const PlanDev& pl) { return plan_k2_is_r16(pl); }
 
 hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const K2Group& grp, const PlanDev& pl) {
     if (!plan_k2_has_group(pl) || grp.n < 1 || grp.n > kMaxNeedleGroup) return hipErrorInvalidValue;
@@ -1356,10 +1287,7 @@ hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const
 
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, 1);
-    if (plan_k2_is_r16(pl) && g_k2_variant == 1) {
-        hipLaunchKernelGGL(k2_rows_p512<true>, dim3(1u << (pl.logN1 + pl.wide)), dim3(512), kR16Lds, st, work, (const float2*)nullptr,
-                           hc_out, pl, 1u);
-    } else if (plan_k2_is_r16(pl)) {
+    if (plan_k2_is_r16(pl)) {
         hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u, 1.0f);
     } else {

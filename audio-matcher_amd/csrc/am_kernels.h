@@ -46,7 +46,7 @@ struct Segment {
     long long a, b;       // [a, b) in the score array
 };
 
-// half = store the work matrix as __half2 per point (r16 plan, K2 variant 0 only)
+// half = store the work matrix as __half2 per point (N = 2^21 plan only)
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half = false);
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
@@ -73,9 +73,11 @@ struct ScanCfg {
 };
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half = false);
+// needles of at most this many samples are correlated by direct summation (no transform)
+constexpr int kDirectMaxNeedle = 64;
+hipError_t launch_direct(hipStream_t st, const Job& job, const float* needle, int s, float out_scale);
 bool plan_is_r16(const PlanDev& pl);
 bool plan_k2_is_r16(const PlanDev& pl);
-extern int g_k2_variant;
 hipError_t fft_kernels_init();
 
 hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats);
@@ -85,10 +87,19 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 constexpr int kInlinePeaks = 4;
 struct SegHeader {
     int n;
-    int overflow;      // bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks; bit 1: theta too high for this chunk
+    int overflow;      // bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks; bit 1: theta too high for this chunk;
+                       // bit 2: more than kInlinePeaks peaks and no room left in the spill arena
     float seg_min;     // (lower bound of the) chunk minimum, for adapting theta
-    int pad_;
+    int arena_off;     // n > kInlinePeaks: the whole list sits at arena.base[arena_off .. arena_off + n)
     am_peak first[kInlinePeaks];
+};
+// Spill area for the peak lists of chunks with more than kInlinePeaks peaks: a bump
+// allocator shared by every chunk of a call (base may be host-mapped memory; cursor is
+// device memory zeroed before the first pick of the call).  base == nullptr: no spill.
+struct PeakArena {
+    am_peak* base;
+    unsigned* cursor;
+    unsigned cap;
 };
 // Which raw scores exist (K3 writes them sparsely): wflags == nullptr means all.
 struct SparseScores {
@@ -100,7 +111,7 @@ struct SparseScores {
 };
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp);
+                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena);
 // writes sumsq_parts(n) partial sums (one per workgroup) to d_parts
 int sumsq_parts(long long n);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts);

@@ -280,7 +280,7 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
-             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp) {
+             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -291,6 +291,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ int overflow;
     __shared__ int cand_tiles[kCandCap];
     __shared__ int cand_n;
+    __shared__ int kept_s, spill_off_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Segment sg = segs[blockIdx.x];
@@ -298,7 +299,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
     if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; }
     if (b - a < 3) {
-        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = 0.f; }
+        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = 0.f; hdr[blockIdx.x].arena_off = -1; }
         return;
     }
     // full tiles [tf, tl) lie completely inside [a, b)
@@ -323,8 +324,89 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     // (x - seg_min >= min_prom) was written (x >= theta); otherwise report it and
     // let the host redo this haystack with theta = -inf.
     if (sp.wflags != nullptr && !((sp.theta - seg_min) < min_prom)) {
-        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; }
+        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
         return;
+    }
+
+    // ---- the chunk's maximum first -------------------------------------------
+    // (1) No score can qualify unless max - chunk_min >= min_prom (prominence <= height -
+    //     chunk_min): an early exit for every chunk without a hit.
+    // (2) With min_distance >= chunk length (the reference's default: 480 s against 60 s
+    //     chunks, audio_matcher.rs:228) the greedy distance filter keeps exactly the first
+    //     peak in (height descending, position ascending) order that passes the prominence
+    //     test and drops all others.  The chunk's maximum -- at its first position -- is
+    //     first in that order, so if it is a peak and passes, it is the chunk's whole answer
+    //     after ONE prominence walk, however many other maxima would qualify.  Anything else
+    //     (maximum at a chunk edge, a plateau reaching the edge, insufficient prominence)
+    //     falls through to the general path below.
+    {
+        __shared__ float bestv_s[kWaves];
+        __shared__ long long bestp_s[kWaves];
+        __shared__ long long peak_i_s, peak_k_s;
+        __shared__ int fast_s;
+        float bv = -FLT_MAX;
+        long long bp = 0x7fffffffffffffffll;
+        auto take = [&](float v, long long pos) { if (v > bv || (v == bv && pos < bp)) { bv = v; bp = pos; } };
+        for (long long i = a + tid; i < head_hi; i += kPeakThreads) take(score_for_cmp(g, sp, i), i);
+        for (long long i = tail_lo + tid; i < b; i += kPeakThreads) take(score_for_cmp(g, sp, i), i);
+        if (has_full) for (long long t = tf + tid; t < tl; t += kPeakThreads) take(stats[t].y, t * kTile);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int olo = __shfl_xor((int)(bp & 0xffffffffll), o), ohi = __shfl_xor((int)(bp >> 32), o);
+            take(ov, ((long long)ohi << 32) | (unsigned)olo);
+        }
+        if (lane == 0) { bestv_s[wv] = bv; bestp_s[wv] = bp; }
+        if (tid == 0) { peak_i_s = 0x7fffffffffffffffll; fast_s = 0; }
+        __syncthreads();
+        bv = bestv_s[0]; bp = bestp_s[0];
+        for (int k = 1; k < kWaves; ++k) take(bestv_s[k], bestp_s[k]);
+        const float M = bv;
+        if (!((M - seg_min) >= min_prom)) {
+            if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
+            return;
+        }
+        if (min_dist >= b - a) {
+            // first position of the maximum: exact for a raw piece, else inside the winning tile
+            const bool in_tile = has_full && bp >= tf * kTile && bp < tl * kTile;
+            if (in_tile) {
+                long long first = 0x7fffffffffffffffll;
+                for (int q = tid; q < kTile; q += kPeakThreads)
+                    if (score_for_cmp(g, sp, bp + q) == M && bp + q < first) first = bp + q;
+                if (first != 0x7fffffffffffffffll) atomicMin((unsigned long long*)&peak_i_s, (unsigned long long)first);
+            } else if (tid == 0) peak_i_s = bp;
+            __syncthreads();
+            const long long pi = peak_i_s;
+            if (tid == 0) {
+                // flat top: x[i-1] < x[i] holds because i is the first position of the chunk maximum
+                long long k = pi + 1;
+                bool ok = pi > a && pi < b - 1;
+                if (ok) {
+                    while (k < b - 1 && score_for_cmp(g, sp, k) == M) ++k;
+                    ok = score_for_cmp(g, sp, k) < M;
+                }
+                peak_k_s = k;
+                fast_s = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (fast_s) {
+                if (wv == 0) {
+                    float prom = 0.0f;
+                    const bool keep = prominence(g, stats, sp, a, b, pi, peak_k_s, M, min_prom, lane, prom);
+                    if (lane == 0) {
+                        if (keep) {
+                            am_peak pk; pk.start = (uint64_t)pi; pk.end = (uint64_t)peak_k_s; pk.height = M; pk.prominence = prom;
+                            hdr[blockIdx.x].first[0] = pk;
+                            my_out[0] = pk;
+                            hdr[blockIdx.x].n = 1; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1;
+                            fast_s = 2;
+                        } else fast_s = 0;
+                    }
+                }
+                __syncthreads();
+                if (fast_s == 2) return;
+            }
+        }
     }
 
     // ---- candidate tiles: prominence <= height - chunk_min (monotone f32
@@ -418,9 +500,23 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
                 my_out[kept++] = pk;
             }
         }
+        // a list longer than the header holds goes to the spill arena as a whole
+        int off = -1, ovf = overflow;
+        if (kept > kInlinePeaks && arena.base != nullptr) {
+            const unsigned o = atomicAdd(arena.cursor, (unsigned)kept);
+            if (o + (unsigned)kept <= arena.cap) off = (int)o;
+            else ovf |= 4;
+        }
+        kept_s = kept; spill_off_s = off;
         hdr[blockIdx.x].n = kept;
-        hdr[blockIdx.x].overflow = overflow;
+        hdr[blockIdx.x].overflow = ovf;
         hdr[blockIdx.x].seg_min = seg_min;
+        hdr[blockIdx.x].arena_off = off;
+    }
+    __syncthreads();
+    if (spill_off_s >= 0) {
+        __threadfence_block();   // thread 0's my_out stores are visible to the block (same CU, L1-coherent within it)
+        for (int i = tid; i < kept_s; i += kPeakThreads) arena.base[spill_off_s + i] = my_out[i];
     }
 }
 
@@ -502,10 +598,10 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp) {
+                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena) {
     if (nsegs <= 0) return hipSuccess;
     hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_hdr, sp);
+                       min_prom, min_dist, d_out, d_hdr, sp, arena);
     return hipGetLastError();
 }
 

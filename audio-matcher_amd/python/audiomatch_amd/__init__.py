@@ -107,6 +107,21 @@ _SIGNATURES = {
                                           C.c_size_t, C.c_float]),
     "am_axpy_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
     "am_set_progress_callback": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "am_set_chunk_progress_callback": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "am_needle_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
+    "am_needle_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]),
+    "am_shard_plan": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "am_pool_create": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_void_p)]),
+    "am_pool_destroy": (None, [C.c_void_p]),
+    "am_pool_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "am_pool_slot": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "am_pool_match_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                      C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                      C.POINTER(C.c_size_t)]),
+    "am_pool_match_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                             C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                             C.POINTER(C.c_size_t)]),
     "am_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "am_profile_reset": (C.c_int, [C.c_int]),
     "am_profile_query": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -296,6 +311,25 @@ class HipConvolve:
         _check(lib().am_match_pcm16(self._h, a.ctypes.data, a.size // 2, C.byref(params), buf, cap, C.byref(n)))
         return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
 
+    def set_option(self, key: str, value: int):
+        """Per-handle "log_n" / "half_pipeline" (-1 = follow the process default)."""
+        _check(lib().am_needle_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_longlong(0)
+        _check(lib().am_needle_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def match_pcm16_batch_device(self, ptrs, frames, params: AmMatchParams, cap_per_hay: int = 256):
+        k = len(ptrs)
+        arr_p = (C.c_void_p * k)(*ptrs)
+        arr_l = (C.c_size_t * k)(*frames)
+        buf = (AmPeak * (cap_per_hay * k))()
+        counts = (C.c_size_t * k)()
+        _check(lib().am_match_pcm16_batch_device(self._h, arr_p, arr_l, k, C.byref(params), buf,
+                                                 cap_per_hay, counts))
+        return _split_batch(buf, counts, k, cap_per_hay)
+
     def match_pcm16_device(self, ptr: int, frames: int, params: AmMatchParams, cap: int = 4096):
         buf = (AmPeak * cap)()
         n = C.c_size_t(0)
@@ -351,11 +385,73 @@ class HipConvolve:
         counts = (C.c_size_t * k)()
         _check(lib().am_match_batch_device(self._h, arr_p, arr_l, k, C.byref(params), buf,
                                            cap_per_hay, counts))
-        out = []
-        for i in range(k):
-            sl = buf[i * cap_per_hay: i * cap_per_hay + counts[i]]
-            out.append([Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in sl])
-        return out
+        return _split_batch(buf, counts, k, cap_per_hay)
+
+
+def _split_batch(buf, counts, k: int, cap: int):
+    return [[Peak(int(b.start), int(b.end), float(b.height), float(b.prominence))
+             for b in buf[i * cap: i * cap + counts[i]]] for i in range(k)]
+
+
+def shard_plan(n_items: int, n_shards: int, shard: int):
+    """am_shard_plan: (first, stride, count) of the items shard `shard` owns (k mod n_shards)."""
+    a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    _check(lib().am_shard_plan(n_items, n_shards, shard, C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+class Pool:
+    """The haystack loop of matcher::run (matcher/mod.rs:42-87) over several GPUs: the needle
+    replicated per device, haystack k matched on slot k mod n (am_pool_*)."""
+
+    def __init__(self, sample_data, devices=None):
+        a = np.ascontiguousarray(sample_data, dtype=np.float32)
+        self._p = C.c_void_p()
+        if devices is None:
+            _check(lib().am_pool_create(a.ctypes.data, a.size, None, 0, C.byref(self._p)))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().am_pool_create(a.ctypes.data, a.size, arr, len(devices), C.byref(self._p)))
+        n = C.c_size_t(0)
+        _check(lib().am_pool_size(self._p, C.byref(n)))
+        self.size = n.value
+
+    def device_of(self, slot: int) -> int:
+        d = C.c_int(0)
+        _check(lib().am_pool_slot(self._p, slot, C.byref(d), None))
+        return d.value
+
+    def match_batch(self, haystacks, params: AmMatchParams, cap_per_hay: int = 256):
+        """Host haystacks (numpy f32 arrays; None = skipped)."""
+        hs = [None if h is None else np.ascontiguousarray(h, dtype=np.float32) for h in haystacks]
+        k = len(hs)
+        arr_p = (C.c_void_p * k)(*[None if h is None else h.ctypes.data for h in hs])
+        arr_l = (C.c_size_t * k)(*[0 if h is None else h.size for h in hs])
+        buf = (AmPeak * max(1, cap_per_hay * k))()
+        counts = (C.c_size_t * max(1, k))()
+        _check(lib().am_pool_match_batch(self._p, arr_p, arr_l, k, C.byref(params), buf, cap_per_hay, counts))
+        return _split_batch(buf, counts, k, cap_per_hay)
+
+    def match_batch_device(self, ptrs, lengths, params: AmMatchParams, cap_per_hay: int = 256):
+        """Resident haystacks: ptrs[k] must live on the device of slot k mod size."""
+        k = len(ptrs)
+        arr_p = (C.c_void_p * k)(*ptrs)
+        arr_l = (C.c_size_t * k)(*lengths)
+        buf = (AmPeak * max(1, cap_per_hay * k))()
+        counts = (C.c_size_t * max(1, k))()
+        _check(lib().am_pool_match_batch_device(self._p, arr_p, arr_l, k, C.byref(params), buf, cap_per_hay, counts))
+        return _split_batch(buf, counts, k, cap_per_hay)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib().am_pool_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def match_multi_device(algos, ptr: int, length: int, params: AmMatchParams, cap_per_needle: int = 256):
@@ -390,6 +486,23 @@ def set_progress_callback(fn):
     cb = PROGRESS_FN(lambda user, k, stage, n: fn(int(k), int(stage), int(n)))
     _progress_keepalive = cb
     _check(lib().am_set_progress_callback(C.cast(cb, C.c_void_p), None))
+
+
+CHUNK_PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int)
+_chunk_progress_keepalive = None
+
+
+def set_chunk_progress_callback(fn):
+    """fn(haystack_index, chunk_index, n_chunks, stage): the per-chunk f1/f2 callbacks of
+    audio_matcher.rs:116-117, 129 (stage 0 = picked up, 1 = done); None clears it."""
+    global _chunk_progress_keepalive
+    if fn is None:
+        _check(lib().am_set_chunk_progress_callback(None, None))
+        _chunk_progress_keepalive = None
+        return
+    cb = CHUNK_PROGRESS_FN(lambda user, k, i, n, stage: fn(int(k), int(i), int(n), int(stage)))
+    _check(lib().am_set_chunk_progress_callback(C.cast(cb, C.c_void_p), None))
+    _chunk_progress_keepalive = cb
 
 
 class Profile:

@@ -7,10 +7,13 @@ from __future__ import annotations
 
 
 def shard_indices(n_items: int, rank: int, world: int):
-    """Haystack k -> rank k mod world."""
+    """Haystack k -> rank k mod world: the rule of the C ABI's am_shard_plan,
+    which the in-process pool (am_pool_*) uses too (a pure function, no device needed)."""
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
-    return list(range(rank, n_items, world))
+    from . import shard_plan
+    first, stride, count = shard_plan(n_items, world, rank)
+    return [first + i * stride for i in range(count)]
 
 
 def owner_of(k: int, world: int) -> int:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AM_ABI_VERSION 1
+#define AM_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -122,6 +122,9 @@ int am_correlate_device(const am_needle* h, const float* d_within, size_t w, int
  * windowing, per-chunk Valid correlation, per-chunk find_peaks
  * (:221-230), offset restore (:126), sort by start (:135) and the overshadow
  * filter (:136-139, 143-160).  Returns peaks sorted by start.
+ * p->scale takes any AM_SCALE_* value, as the reference's generic calc_chunks takes any
+ * CorrelateAlgo: with AM_SCALE_MY every window is scaled by its own
+ * 1 / (sum(needle^2) * within.len()) (audio_matcher.rs:442-448).
  * On AM_ERR_CAPACITY *n_out holds the number of peaks found. */
 int am_match(const am_needle* h, const float* haystack, size_t len,
              const am_match_params* p, am_peak* out, size_t cap, size_t* n_out);
@@ -185,14 +188,51 @@ int am_synth_uniform_device(int device, float* d_out, uint32_t seed, uint32_t st
 /* d_dst[i] += gain * d_src[i]  (plants a needle into a haystack) */
 int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float gain);
 
-/* ---- progress hook ---------------------------------------------------------- */
+/* ---- the haystack batch over every GPU of a node ----------------------------- */
+/* matcher::run's per-file loop (matcher/mod.rs:42-87) sharded over devices: haystacks are
+ * independent given the needle (audio_matcher.rs:114-131), so haystack k goes to pool slot
+ * k mod n_dev -- no exchange step, no collective; results are gathered on the host.
+ * am_shard_plan is that rule as a pure function (no device needed): shard `shard` of
+ * `n_shards` owns items first, first + stride, ... (count of them). */
+int am_shard_plan(size_t n_items, size_t n_shards, size_t shard, size_t* first, size_t* stride, size_t* count);
+
+/* A pool = LibConvolve::new(sample_data) (audio_matcher.rs:289) replicated on each listed
+ * device (needle + its spectrum per device, built locally).  devices == NULL: every
+ * visible device, in ordinal order.  A device may be listed more than once (its slots then
+ * share that device's queue). */
+typedef struct am_pool am_pool;
+int am_pool_create(const float* needle, size_t n, const int* devices, size_t n_dev, am_pool** out);
+void am_pool_destroy(am_pool* pool);
+int am_pool_size(const am_pool* pool, size_t* n_dev);
+/* slot's device ordinal and its needle handle (borrowed: valid until am_pool_destroy) */
+int am_pool_slot(const am_pool* pool, size_t slot, int* device, const am_needle** needle);
+/* The whole loop on HOST buffers: one submit thread per slot takes its haystacks in order;
+ * a second thread per slot copies haystack i+1 into the other half of a two-slot HBM ring
+ * while haystack i is matched, so the link and the kernels overlap.  out / n_out are laid
+ * out as in am_match_batch_device (cap_per_hay slots per haystack); every submit thread
+ * writes only its own haystacks' slots.  Returns the worst status over all haystacks. */
+int am_pool_match_batch(am_pool* pool, const float* const* haystacks, const size_t* lens, size_t n_hay,
+                        const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
+/* Same with resident haystacks: d_haystacks[k] must live on the device of slot k mod n_dev. */
+int am_pool_match_batch_device(am_pool* pool, const float* const* d_haystacks, const size_t* lens, size_t n_hay,
+                               const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
+
+/* ---- progress hooks ---------------------------------------------------------- */
 /* The two-stage progress callbacks of calc_chunks (audio_matcher.rs:102-117, 129:
- * f1 when a chunk is picked up, f2 when it is done).  All chunks of a haystack
- * run in one set of launches here, so the hook fires per haystack: stage 0 with
- * its chunk count when it is queued, stage 1 when its peaks are back on the host.
- * Process-wide; pass NULL to clear. */
+ * f1 when a chunk is picked up, f2 when it is done).
+ * Per haystack (aggregate): stage 0 with its chunk count when it is queued, stage 1 when
+ * its peaks are back on the host.
+ * Per chunk (the reference's granularity): all chunks of a haystack run in one set of
+ * launches here, so stage 0 fires for chunks 0..n-1 in order when the haystack is queued
+ * and stage 1 for chunks 0..n-1 in order when its results have landed; like the
+ * reference's f1/f2, every chunk sees stage 0 before stage 1.
+ * haystack_index is the index in the caller's batch (pool calls included; pool submit
+ * threads call back concurrently).  Process-wide; a running call keeps the callbacks it
+ * started with; pass NULL to clear. */
 typedef void (*am_progress_fn)(void* user, size_t haystack_index, int stage, size_t n_chunks);
 int am_set_progress_callback(am_progress_fn fn, void* user);
+typedef void (*am_chunk_progress_fn)(void* user, size_t haystack_index, size_t chunk_index, size_t n_chunks, int stage);
+int am_set_chunk_progress_callback(am_chunk_progress_fn fn, void* user);
 
 /* ---- measurement hooks ---------------------------------------------------- */
 /* When enabled every kernel launch of the pipeline on `device` is bracketed by
@@ -204,20 +244,25 @@ int am_profile_enable(int device, int on);
 int am_profile_reset(int device);
 int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t* launches);
 
-/* options:
- *   "log_n" (0 = auto), "pairs_per_group", "k2_variant" (0/1), "lanes" (1/2),
- *       "profile_mask": tuning / measurement knobs
+/* Process-wide option DEFAULTS.  A call reads them once on entry, so changing one never
+ * affects a call that is already running.
+ *   "log_n" (0 = auto), "pairs_per_group", "profile_mask": tuning / measurement knobs
  *   "batch_overlap" (0/1, default 1): in am_match_batch_device pick the peaks of haystack k
  *       on a second stream beside the transforms of haystack k+1
- *   "vmm_work" (0 = off, else MB per physical chunk): measurement only; backs the work
- *       matrix with hipMemCreate chunks of that size (fragment size)
  *   "needle_group" (1..8, default 8): how many needles of am_match_multi_device share
  *       one forward row transform of the haystack (1 = one row pass per needle)
  *   "half_pipeline" (0/1): store the transform's work matrix in half precision
  *       (BASELINE config 5).  Butterflies stay f32; scores then carry an absolute
- *       error of about 1e-5 of the chunk's score range, hit offsets are unaffected. */
+ *       error of about 1e-5 of the chunk's score range, hit offsets are unaffected.
+ *   "dense_scores" (0/1): write every raw score from the inverse pass (threshold -inf)
+ *       instead of only the tiles that can matter to the peak pick; results are
+ *       identical, this is the worst case of the sparse-score path for measurements. */
 int am_set_option(const char* key, long long value);
 int am_get_option(const char* key, long long* value);
+/* "log_n" and "half_pipeline" per needle handle: -1 = follow the process default (initial
+ * state), otherwise the handle's own value, which wins over the default. */
+int am_needle_set_option(am_needle* h, const char* key, long long value);
+int am_needle_get_option(const am_needle* h, const char* key, long long* value);
 
 #ifdef __cplusplus
 }

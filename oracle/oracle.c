@@ -67,9 +67,11 @@ float orc_inv_autocorr(const float* needle, size_t s) {
 
 static size_t next_pow2(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
 
-size_t orc_correlate(const float* within, size_t w, const float* needle, size_t s,
-                     int mode, int scale, int fft_policy, int precision,
-                     float* out, size_t cap) {
+/* spec / spec_pad: an optional cached needle spectrum for pad length spec_pad
+ * (ORC_FFT_POW2_CACHED, see orc_calc_chunks) */
+static size_t correlate_impl(const float* within, size_t w, const float* needle, size_t s,
+                             int mode, int scale, int fft_policy, int precision,
+                             float* out, size_t cap, const void* spec, size_t spec_pad) {
     if (w == 0 || s == 0) return (size_t)-1;
     size_t full_len = w + s - 1;
     size_t len = orc_mode_len(w, s, mode), start = orc_mode_start(w, s, mode);
@@ -89,10 +91,11 @@ size_t orc_correlate(const float* within, size_t w, const float* needle, size_t 
             full[j] = acc;
         }
     } else {
-        size_t pad_len = fft_policy == ORC_FFT_POW2 ? next_pow2(full_len) : full_len; /* :421 */
+        size_t pad_len = fft_policy == ORC_FFT_REFERENCE ? full_len : next_pow2(full_len); /* :421 */
+        const void* use = (spec && spec_pad == pad_len) ? spec : NULL;
         rc = precision == ORC_PREC_F32
-                 ? correlate_full_f(within, w, needle, s, pad_len, full)
-                 : correlate_full_d(within, w, needle, s, pad_len, full);
+                 ? correlate_full_f(within, w, needle, s, pad_len, full, use)
+                 : correlate_full_d(within, w, needle, s, pad_len, full, use);
     }
     if (rc) { free(full); return (size_t)-1; }
     /* scaling: every factor applied as an f32 multiply like scale_slice (:246-252) */
@@ -105,6 +108,12 @@ size_t orc_correlate(const float* within, size_t w, const float* needle, size_t 
     }
     free(full);
     return len;
+}
+
+size_t orc_correlate(const float* within, size_t w, const float* needle, size_t s,
+                     int mode, int scale, int fft_policy, int precision,
+                     float* out, size_t cap) {
+    return correlate_impl(within, w, needle, s, mode, scale, fft_policy, precision, out, cap, NULL, 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -236,6 +245,7 @@ typedef struct {
     size_t chunk, window; float min_prom; size_t min_dist;
     int scale, policy, prec;
     size_t n_windows;
+    const void* spec; size_t spec_pad;   /* cached needle spectrum (ORC_FFT_POW2_CACHED) */
     size_t next;                 /* work counter (par_bridge analogue) */
     pthread_mutex_t mu;
     orc_peak** per_window; size_t* per_window_n;
@@ -256,8 +266,8 @@ static void* cc_worker(void* arg) {
         size_t v = w - J->s + 1;
         float* sc = (float*)malloc(sizeof(float) * v);
         if (!sc) { J->failed = 1; continue; }
-        if (orc_correlate(J->hay + off, w, J->needle, J->s, ORC_MODE_VALID, J->scale,
-                          J->policy, J->prec, sc, v) != v) { J->failed = 1; free(sc); continue; } /* :120-122 */
+        if (correlate_impl(J->hay + off, w, J->needle, J->s, ORC_MODE_VALID, J->scale,
+                           J->policy, J->prec, sc, v, J->spec, J->spec_pad) != v) { J->failed = 1; free(sc); continue; } /* :120-122 */
         size_t cap = 16, n;
         orc_peak* pk = (orc_peak*)malloc(sizeof(orc_peak) * cap);
         n = orc_find_peaks(sc, v, J->min_prom, J->min_dist, pk, cap);                     /* :124 */
@@ -300,6 +310,17 @@ size_t orc_calc_chunks(uint32_t sr, const float* haystack, size_t h,
     J.chunk = chunk; J.window = chunk + overlap; J.min_prom = min_prominence; J.min_dist = min_distance;
     J.scale = scale; J.policy = fft_policy; J.prec = precision;
     J.n_windows = (h + chunk - 1) / chunk;
+    void* spec = NULL;
+    if (fft_policy == ORC_FFT_POW2_CACHED) {
+        /* the "good CPU implementation" row of BASELINE.md: power-of-two padding and the
+         * needle transformed ONCE for all full-length windows (the reference re-transforms
+         * it per chunk, audio_matcher.rs:430) */
+        size_t w0 = h < J.window ? h : J.window;
+        J.spec_pad = next_pow2(w0 + s - 1);
+        spec = precision == ORC_PREC_F32 ? (void*)needle_spectrum_f(needle, s, J.spec_pad)
+                                         : (void*)needle_spectrum_d(needle, s, J.spec_pad);
+        J.spec = spec;
+    }
     J.per_window = (orc_peak**)calloc(J.n_windows, sizeof(orc_peak*));
     J.per_window_n = (size_t*)calloc(J.n_windows, sizeof(size_t));
     pthread_mutex_init(&J.mu, NULL);
@@ -321,6 +342,7 @@ size_t orc_calc_chunks(uint32_t sr, const float* haystack, size_t h,
         free(J.per_window[i]);
     }
     free(J.per_window); free(J.per_window_n);
+    free(spec);
     pthread_mutex_destroy(&J.mu);
     /* stable sort by start: insertion-merge via index tiebreak */
     {

@@ -56,7 +56,9 @@ enum { ORC_SCALE_NONE = 0, ORC_SCALE_LIB = 1, ORC_SCALE_MY = 2 };
 enum {
     ORC_FFT_REFERENCE = 0, /* pad_len = w+s-1 exactly as audio_matcher.rs:421 (Bluestein if needed) */
     ORC_FFT_POW2 = 1,      /* pad_len = next power of two (same result, faster checker) */
-    ORC_FFT_DIRECT = 2     /* O(w*s) direct summation in f64 (tiny shapes, exact) */
+    ORC_FFT_DIRECT = 2,    /* O(w*s) direct summation in f64 (tiny shapes, exact) */
+    ORC_FFT_POW2_CACHED = 3 /* orc_calc_chunks only: ORC_FFT_POW2 with the needle spectrum computed
+                              once per call and shared by all full-length windows */
 };
 /* arithmetic of the transforms */
 enum { ORC_PREC_F64 = 0, ORC_PREC_F32 = 1 };

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MODE_FULL, MODE_SAME, MODE_VALID = 0, 1, 2
 SCALE_NONE, SCALE_LIB, SCALE_MY = 0, 1, 2
-FFT_REFERENCE, FFT_POW2, FFT_DIRECT = 0, 1, 2
+FFT_REFERENCE, FFT_POW2, FFT_DIRECT, FFT_POW2_CACHED = 0, 1, 2, 3
 PREC_F64, PREC_F32 = 0, 1
 
 

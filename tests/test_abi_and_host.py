@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(amlib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", amlib.LIB_PATH], text=True)
     exported = set(re.findall(r"\bT (am_[a-z0-9_]+)\b", out))
     assert set(header_symbols()) <= exported
-    assert amlib.lib().am_abi_version() == 1
+    assert amlib.lib().am_abi_version() == 2
 
 
 def test_header_cites_reference_for_every_entry_point():
@@ -122,6 +122,58 @@ def test_bench_and_smoke_refuse_to_run_without_a_gpu(amlib):
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs a HIP device" in r.stderr
+
+
+def test_shard_plan_is_a_partition(amlib):
+    """am_shard_plan (haystack k -> shard k mod n) needs no device: every item
+    belongs to exactly one shard, shards differ in size by at most one."""
+    for n_items in (0, 1, 7, 1000):
+        for n_shards in (1, 2, 3, 8):
+            seen = []
+            counts = []
+            for sh in range(n_shards):
+                first, stride, count = amlib.shard_plan(n_items, n_shards, sh)
+                assert (first, stride) == (sh, n_shards)
+                seen += [first + i * stride for i in range(count)]
+                counts.append(count)
+            assert sorted(seen) == list(range(n_items)) and max(counts) - min(counts) <= 1
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.shard_plan(10, 2, 2)
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.shard_plan(10, 0, 0)
+    from audiomatch_amd import sharding
+    assert sharding.shard_indices(10, 1, 4) == [1, 5, 9]
+
+
+def test_pool_needs_a_device(amlib):
+    if amlib.device_count() > 0:
+        pytest.skip("a HIP device is present; covered by the gpu tests")
+    with pytest.raises(amlib.AudioMatchError) as ei:
+        amlib.Pool([1.0, 2.0, 3.0])
+    assert ei.value.code == amlib.AM_ERR_NO_DEVICE
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.Pool([1.0, 2.0, 3.0], [0, 1])
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`bench.py --gpus 2 --dry-shard`: the parent starts two fresh rank processes (it makes
+    no HIP call itself), every rank prints its shard of the 1000-haystack batch (k mod N) and
+    -- on a box without a GPU -- stops with an explicit error instead of a number."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-shard"],
+                       capture_output=True, text=True, timeout=300)
+    plans = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(p["rank"] for p in plans) == [0, 1] and all(p["world"] == 2 for p in plans)
+    assert [p["count"] for p in sorted(plans, key=lambda p: p["rank"])] == [500, 500]
+    assert sorted(plans, key=lambda p: p["rank"])[1]["first"] == [1, 3, 5]
+    sys.path.insert(0, os.path.join(ROOT, "audio-matcher_amd", "python"))
+    import audiomatch_amd
+    if audiomatch_amd.device_count() < 1:
+        assert r.returncode != 0 and r.stderr.count("needs a HIP device") == 2
+    # a rank count that disagrees with the launcher's world size is refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-shard"],
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
 
 
 def test_isa_has_no_store_data_hazard(tmp_path):

@@ -15,8 +15,7 @@ def test_k1_reference_known_answer(gpu, oracle):
     got = algo.correlate_with_sample(within, gpu.Mode.Valid, False)
     expect = np.array([6 * j - 52 for j in range(18)], dtype=np.float32)
     assert got.shape == expect.shape
-    assert np.abs(got - expect).max() < 1.2e-5 * 60  # reference tolerance is absolute 1.2e-5 on O(1) data; values here reach 52
-    assert np.abs(got - expect).max() < 1e-3
+    assert np.abs(got - expect).max() < 1.2e-5   # the reference's own bound (audio_matcher.rs:511)
 
 
 def test_k5_bench_shape(gpu, oracle):

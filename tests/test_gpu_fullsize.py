@@ -110,6 +110,34 @@ def test_batch_equals_singles_full_size(full):
     assert [(q.start, q.height) for q in res[2]] == [(q.start, q.height) for q in res[0]]
 
 
+def test_config4_32_needles_full_size(gpu):
+    """BASELINE configs[3] at its stated shape on one GPU: 32 needles (streams 2001..2032,
+    SURVEY.md 8d) against one 1 h haystack, each needle planted twice; the shared forward
+    pass + grouped row transforms (4 groups of 8) find exactly the planted offsets, on the
+    dense and on the sparse score path, and agree with separate single-needle calls."""
+    nn = 32
+    needles = [gpu.synth_uniform_device(0, S, seed=1, stream=2001 + j) for j in range(nn)]
+    algos = [gpu.HipConvolve.from_device(0, n.ptr, S) for n in needles]
+    hay = gpu.synth_uniform_device(0, H, seed=1, stream=1)
+    plants = [[(20 + 55 * j) * SR + 13 * j, (20 + 55 * j + 1790) * SR + 7 * j] for j in range(nn)]
+    for j, n in enumerate(needles):
+        for t in plants[j]:
+            gpu.axpy_device(0, hay, t, n.ptr, S, 1.0)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=480.0, prominence=0.13)
+    p = cfg.params(SR, gpu.Scale.LIB)
+    for _ in range(2):
+        res = gpu.match_multi_device(algos, hay.ptr, H, p)
+        assert [[q.start for q in r] for r in res] == plants
+        assert all(abs(q.height - 1.0) < 0.03 and q.prominence > 0.9 for r in res for q in r)
+    for j in (0, 7, 8, 31):
+        one = algos[j].match_device(hay.ptr, H, p)
+        assert [(q.start, q.end) for q in one] == [(q.start, q.end) for q in res[j]]
+        for a, b in zip(one, res[j]):
+            assert abs(a.height - b.height) < 2e-6 and abs(a.prominence - b.prominence) < 2e-6
+    for b in needles + [hay]:
+        b.free()
+
+
 def test_offsets_beyond_2_to_31_samples(gpu):
     """A 14 h haystack (2.22e9 samples, 8.9 GB resident): score indices, block and chunk
     arithmetic beyond 2^31, hits before and after that mark, found on the dense and the

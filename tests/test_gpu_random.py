@@ -110,25 +110,5 @@ def test_random_wide_plan(gpu, oracle, seed):
     algo = gpu.HipConvolve(needle)
     got = algo.correlate_with_sample(win, gpu.Mode.Valid, True)
     ref = oracle.correlate(win, needle, oracle.MODE_VALID, oracle.SCALE_LIB)
-    bad = np.nonzero(np.abs(got - ref) >= TOL)[0]
-    if bad.size:   # diagnostics: is the error tied to the handle (its spectrum) or to that one call?
-        again = algo.correlate_with_sample(win, gpu.Mode.Valid, True)
-        fresh = gpu.HipConvolve(needle).correlate_with_sample(win, gpu.Mode.Valid, True)
-        err = np.abs(got - ref)
-        cols = np.unique(bad % 16384)
-        percol = {int(c): float(err[c::16384].max()) for c in cols[:8]}
-        big = np.nonzero(err >= 2e-5)[0]
-        bcols = big % 16384
-        rows_of_first = (big[bcols == bcols[0]] // 16384).tolist()
-        even_max = float(err[(np.arange(err.size) % 2) == 0].max())
-        low_max = float(err[(np.arange(err.size) % 16384) < 512].max())
-        print("WIDE-DIAG cols mod 32:", np.unique(bcols % 32).tolist(), "col range", int(bcols.min()), int(bcols.max()),
-              "n cols", int(np.unique(bcols).size), "even-col max err %.3e" % even_max, "cols<512 max err %.3e" % low_max,
-              "rows of col %d:" % int(bcols[0]), rows_of_first[:40], "n", len(rows_of_first),
-              "cols//512 present:", np.unique(bcols // 512).tolist())
-        raise AssertionError((getattr(gpu, "gpu_identity", "?"), bad.size, bad[:6].tolist(), float(err.max()), s, h,
-                              "same handle again: max err %.3e" % float(np.abs(again - ref).max()),
-                              "fresh handle: max err %.3e" % float(np.abs(fresh - ref).max()),
-                              "bad columns", cols[:16].tolist(), percol,
-                              "errors >= 2e-5: %d" % int((err >= 2e-5).sum()),
-                              "cols >= 2e-5", np.unique(np.nonzero(err >= 2e-5)[0] % 16384)[:40].tolist()))
+    err = np.abs(got - ref)
+    assert float(err.max()) < TOL, (getattr(gpu, "gpu_identity", "?"), float(err.max()), int(np.argmax(err)), s, h)

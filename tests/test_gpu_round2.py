@@ -1,0 +1,394 @@
+"""GPU tests of the round-2 boundary work, all through the C ABI:
+the reference's overshadow / peak known answers driven through am_match itself, the
+entry points no test called before, per-chunk progress, MyConvolve scaling in
+calc_chunks, per-handle options, the dense / sparse / redo score paths and the
+multi-device pool (am_pool_*)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def key(r):
+    return [(q.start, q.end, q.height, q.prominence) for q in r]
+
+
+def assert_same(got, exp, tol=TOL):
+    assert [g.start for g in got] == [e[0] for e in exp]
+    assert [g.end for g in got] == [e[1] for e in exp]
+    for g, e in zip(got, exp):
+        assert abs(g.height - e[2]) < tol and abs(g.prominence - e[3]) < tol
+
+
+# ---------------------------------------------------------------------------
+# the reference's own known answers, through the shipped entry points
+# ---------------------------------------------------------------------------
+K2_DATA = [0.0, 0.7, 0.5, 1.0, 0.5, 0.8, 0.0]          # audio_matcher.rs:168
+
+
+def spike_params(gpu, distance_s, min_distance=0):
+    # sr = 1 as in the reference's test (audio_matcher.rs:189): sample index == seconds
+    return gpu.AmMatchParams(sr=1, chunk=len(K2_DATA), overlap=0, min_prominence=0.0,
+                             min_distance=min_distance, overshadow_distance_s=float(distance_s),
+                             scale=int(gpu.Scale.NONE))
+
+
+def test_k2_k3_known_answers_through_am_match(gpu):
+    """audio_matcher.rs:167-218 through am_match: a one-sample needle [1.0] makes the Valid
+    correlation the haystack itself, so find_peaks sees exactly the reference's test data.
+    K2: prominences 0.2 / 1.0 / 0.3 at 1 / 3 / 5.  K3: with distance 3 s the neighbours of
+    the tallest peak (2 s away, lower prominence) are overshadowed, with 2 s (strict <)
+    nobody is; the tallest is never overshadowed."""
+    algo = gpu.HipConvolve([1.0])
+    hay = np.array(K2_DATA, np.float32)
+    for _ in range(2):
+        got = algo.match(hay, spike_params(gpu, 2))
+        assert [(g.start, g.end) for g in got] == [(1, 2), (3, 4), (5, 6)]
+        for g, prom, height in zip(got, (0.2, 1.0, 0.3), (0.7, 1.0, 0.8)):
+            assert abs(g.prominence - prom) < 1e-6 and abs(g.height - height) < 1e-6   # reference tolerance (:181)
+        got = algo.match(hay, spike_params(gpu, 3))
+        assert [(g.start, g.prominence) for g in got] == [(3, 1.0)]
+    # the same table through the device-resident and the batch entry points
+    buf = gpu.DeviceBuffer.from_numpy(0, hay)
+    assert [g.start for g in algo.match_device(buf.ptr, hay.size, spike_params(gpu, 3))] == [3]
+    res = algo.match_batch_device([buf.ptr, buf.ptr], [hay.size, hay.size], spike_params(gpu, 2))
+    assert [[g.start for g in r] for r in res] == [[1, 3, 5], [1, 3, 5]]
+
+
+def test_k3_truth_table_pairs_through_am_match(gpu):
+    """audio_matcher.rs:187-218 pair by pair: two peaks 2 s apart (sr = 1); the lower one is
+    dropped iff distance > 2 s; equal prominence drops nobody (strict >)."""
+    algo = gpu.HipConvolve([1.0])
+    lo_hi = np.array([0, 0.2, 0, 1.0, 0], np.float32)      # peaks at 1 (prom .2) and 3 (prom 1)
+    hi_lo = np.array([0, 1.0, 0, 0.3, 0], np.float32)      # peaks at 1 (prom 1) and 3 (prom .3)
+    same = np.array([0, 0.5, 0, 0.5, 0], np.float32)
+    for hay, tall in ((lo_hi, 3), (hi_lo, 1)):
+        p = spike_params(gpu, 3); p.chunk = hay.size
+        assert [g.start for g in algo.match(hay, p)] == [tall]
+        p = spike_params(gpu, 2); p.chunk = hay.size
+        assert [g.start for g in algo.match(hay, p)] == [1, 3]
+    p = spike_params(gpu, 3); p.chunk = same.size
+    assert [g.start for g in algo.match(same, p)] == [1, 3]
+
+
+def test_k1_known_answer_at_reference_tolerance(gpu):
+    """audio_matcher.rs:490-517 at the reference's own bound (abs diff < 1.2e-5, :511): tiny
+    needles are summed directly, which is exact on this integer data.  The transform path on
+    the same input (forced 2^10 plan) is reported and held to the same bound relative to the
+    data's magnitude (its values reach 52; ten f32 butterfly stages)."""
+    within = np.arange(-10, 10, dtype=np.float32)
+    expect = np.array([6 * j - 52 for j in range(18)], dtype=np.float32)
+    algo = gpu.HipConvolve([1.0, 2.0, 3.0])
+    got = algo.correlate_with_sample(within, gpu.Mode.Valid, False)
+    assert np.abs(got - expect).max() < 1.2e-5
+    algo.set_option("log_n", 10)
+    fft = algo.correlate_with_sample(within, gpu.Mode.Valid, False)
+    err = float(np.abs(fft - expect).max())
+    print("K1 KAT: direct max err %.3g, 2^10 transform max err %.3g" % (float(np.abs(got - expect).max()), err))
+    assert err / np.abs(expect).max() < 1.2e-5
+
+
+# ---------------------------------------------------------------------------
+# entry points no test called before
+# ---------------------------------------------------------------------------
+def pcm_case(oracle, sr, needle_s, hay_s, plants_s, seed):
+    rng = np.random.default_rng(seed)
+    s, h = int(needle_s * sr), int(hay_s * sr)
+    needle_lr = rng.integers(-9000, 9000, size=2 * s).astype(np.int16)
+    hay_lr = rng.integers(-9000, 9000, size=2 * h).astype(np.int32)
+    for t in plants_s:
+        off = int(t * sr)
+        hay_lr[2 * off:2 * (off + s)] += needle_lr
+    return needle_lr, np.clip(hay_lr, -32768, 32767).astype(np.int16)
+
+
+def test_pcm16_device_and_batch_entry_points(gpu, oracle):
+    """am_match_pcm16_device / am_match_pcm16_batch_device / am_pcm_s16_stereo_to_mono_device
+    (mp3_reader.rs:12, 28-37 down-mix, fused or as its own kernel) against the oracle."""
+    sr = 48000
+    needle_lr, hay_a = pcm_case(oracle, sr, 2.0, 75.0, [7.0, 51.25], 5)
+    _, hay_b = pcm_case(oracle, sr, 2.0, 31.0, [], 6)
+    off = int(19.5 * sr)
+    hay_b = hay_b.astype(np.int32)
+    hay_b[2 * off:2 * off + needle_lr.size] += needle_lr
+    hay_b = np.clip(hay_b, -32768, 32767).astype(np.int16)
+    needle = oracle.pcm_s16_stereo_to_mono(needle_lr)
+    cfg = gpu.Config(chunk_size_s=30.0, overlap_length_s=2.0, distance_s=10.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve.from_pcm16(needle_lr)
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in (hay_a, hay_b)]
+    frames = [hay_a.size // 2, hay_b.size // 2]
+    exps = [oracle.calc_chunks(sr, oracle.pcm_s16_stereo_to_mono(h), needle, p.chunk, p.overlap, 0.13,
+                               p.min_distance, 10.0) for h in (hay_a, hay_b)]
+    assert [e[0] for e in exps[0]] == [7 * sr, int(51.25 * sr)] and [e[0] for e in exps[1]] == [off]
+    for _ in range(2):                                  # dense, then sparse score path
+        for b, f, e in zip(bufs, frames, exps):
+            assert_same(algo.match_pcm16_device(b.ptr, f, p), e)
+        res = algo.match_pcm16_batch_device([b.ptr for b in bufs] + [bufs[0].ptr], frames + [frames[0]], p)
+        for r, e in zip(res, exps + [exps[0]]):
+            assert_same(r, e)
+    # the stand-alone down-mix on device memory: bit-exact
+    mono = gpu.DeviceBuffer(0, 4 * frames[0])
+    gpu._check(gpu.lib().am_pcm_s16_stereo_to_mono_device(0, bufs[0].ptr, frames[0], mono.ptr))
+    assert np.array_equal(mono.to_numpy(np.float32, frames[0]), oracle.pcm_s16_stereo_to_mono(hay_a))
+    # ... and what the f32 entry point finds on that buffer equals the fused ingest
+    a32 = gpu.HipConvolve(needle)
+    assert key(a32.match_device(mono.ptr, frames[0], p)) == key(algo.match_pcm16_device(bufs[0].ptr, frames[0], p))
+
+
+# ---------------------------------------------------------------------------
+# per-chunk progress (audio_matcher.rs:116-117, 129)
+# ---------------------------------------------------------------------------
+def test_per_chunk_progress_events(gpu, oracle):
+    sr = 8000
+    needle = oracle.synth_uniform(3, 0, 0, sr)
+    hay = oracle.synth_uniform(3, 1, 0, 30 * sr)           # 3 chunks of 10 s
+    cfg = gpu.Config(chunk_size_s=10.0, overlap_length_s=1.0, distance_s=5.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    chunk_ev, hay_ev = [], []
+    gpu.set_chunk_progress_callback(lambda k, i, n, stage: chunk_ev.append((k, i, n, stage)))
+    gpu.set_progress_callback(lambda k, stage, n: hay_ev.append((k, stage, n)))
+    try:
+        algo.match(hay, p)
+        assert chunk_ev == [(0, 0, 3, 0), (0, 1, 3, 0), (0, 2, 3, 0), (0, 0, 3, 1), (0, 1, 3, 1), (0, 2, 3, 1)]
+        assert hay_ev == [(0, 0, 3), (0, 1, 3)]
+        del chunk_ev[:], hay_ev[:]
+        b = gpu.DeviceBuffer.from_numpy(0, hay)
+        algo.match_batch_device([b.ptr, b.ptr], [hay.size, 12 * sr], p)    # 3 chunks and 2 chunks
+        for k, n in ((0, 3), (1, 2)):
+            mine = [e for e in chunk_ev if e[0] == k]
+            assert mine == [(k, i, n, 0) for i in range(n)] + [(k, i, n, 1) for i in range(n)]
+        assert hay_ev == [(0, 0, 3), (1, 0, 2), (0, 1, 3), (1, 1, 2)]
+    finally:
+        gpu.set_chunk_progress_callback(None)
+        gpu.set_progress_callback(None)
+    del chunk_ev[:]
+    algo.match(hay, p)
+    assert chunk_ev == []
+
+
+# ---------------------------------------------------------------------------
+# calc_chunks with MyConvolve's scaling (audio_matcher.rs:442-448)
+# ---------------------------------------------------------------------------
+def test_calc_chunks_with_my_scaling(gpu, oracle):
+    """AM_SCALE_MY on am_match: every window is scaled by 1 / (sum(needle^2) * within.len()),
+    so the shorter windows at the end of a haystack get their own factor (and prominences
+    relative to it).  Relative tolerance: the scores are of order 1 / window."""
+    sr = 8000
+    s = 2 * sr
+    needle = oracle.synth_uniform(7, 0, 0, s)
+    hay = oracle.synth_uniform(7, 1, 0, 70 * sr)             # chunks at 0, 20, 40, 60 s; window 25 s
+    for t in (5.0, 31.0, 47.5, 63.0):                        # the last plant sits in the 10 s tail window
+        off = int(t * sr)
+        hay[off:off + s] += needle
+    window = 25 * sr
+    prom = 0.13 / window                                     # the usual threshold in MyConvolve's units
+    p = gpu.AmMatchParams(sr=sr, chunk=20 * sr, overlap=5 * sr, min_prominence=prom, min_distance=0,
+                          overshadow_distance_s=4.0, scale=int(gpu.Scale.MY))
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, prom, 0, 4.0, scale=oracle.SCALE_MY)
+    assert [e[0] for e in exp] == [int(t * sr) for t in (5.0, 31.0, 47.5, 63.0)]
+    assert exp[3][2] > 2 * exp[0][2]                          # the tail window's factor is larger
+    algo = gpu.HipConvolve(needle)
+    for _ in range(2):
+        got = algo.match(hay, p)
+        assert [(g.start, g.end) for g in got] == [(e[0], e[1]) for e in exp]
+        for g, e in zip(got, exp):
+            assert abs(g.height - e[2]) < 1e-4 * e[2] and abs(g.prominence - e[3]) < 1e-4 * e[3]
+    # a haystack shorter than one window: only a "tail" window exists
+    short = hay[: 12 * sr]
+    exp = oracle.calc_chunks(sr, short, needle, p.chunk, p.overlap, 0.13 / (12 * sr), 0, 4.0, scale=oracle.SCALE_MY)
+    p.min_prominence = 0.13 / (12 * sr)
+    got = algo.match(short, p)
+    assert [g.start for g in got] == [e[0] for e in exp] == [5 * sr]
+    assert abs(got[0].height - exp[0][2]) < 1e-4 * exp[0][2]
+
+
+# ---------------------------------------------------------------------------
+# options: per call / per handle
+# ---------------------------------------------------------------------------
+def test_per_handle_plan_and_concurrent_calls(gpu, oracle):
+    """log_n is a property of the handle (am_needle_set_option), not of the process: two
+    handles with different plans used from two threads at once give the answers they give
+    alone, and the process default is untouched."""
+    sr = 8000
+    needle = oracle.synth_uniform(9, 0, 0, 3 * sr)
+    hay = oracle.synth_uniform(9, 1, 0, 120 * sr)
+    for t in (10.0, 77.0):
+        off = int(t * sr)
+        hay[off:off + needle.size] += needle
+    cfg = gpu.Config(chunk_size_s=30.0, overlap_length_s=3.0, distance_s=10.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 10.0)
+    a, b = gpu.HipConvolve(needle), gpu.HipConvolve(needle)
+    a.set_option("log_n", 16)
+    b.set_option("log_n", 18)
+    assert (a.get_option("log_n"), b.get_option("log_n"), gpu.get_option("log_n")) == (16, 18, 0)
+    alone = [key(a.match(hay, p)), key(b.match(hay, p))]
+    out = [[], []]
+
+    def work(i, algo):
+        for _ in range(6):
+            out[i].append(key(algo.match(hay, p)))
+    th = [threading.Thread(target=work, args=(0, a)), threading.Thread(target=work, args=(1, b))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in (0, 1):
+        assert all(r == alone[i] for r in out[i])
+    assert_same(a.match(hay, p), exp)
+    assert_same(b.match(hay, p), exp)
+    with pytest.raises(gpu.AudioMatchError):
+        a.set_option("log_n", 99)
+    a.set_option("log_n", -1)
+    assert a.get_option("log_n") == -1
+
+
+def test_dense_scores_option_is_result_neutral(gpu, oracle):
+    """dense_scores = 1 (every raw score written, the worst case of the sparse path) gives
+    bit-identical results to the sparse path."""
+    sr = 44100
+    needle = oracle.synth_uniform(13, 0, 0, 4 * sr)
+    hay = oracle.synth_uniform(13, 1, 0, 200 * sr)
+    for t in (33.0, 150.5):
+        off = int(t * sr)
+        hay[off:off + needle.size] += needle
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=4.0, distance_s=30.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    first = key(algo.match(hay, p))            # no history: dense
+    sparse = key(algo.match(hay, p))           # sparse
+    gpu.set_option("dense_scores", 1)
+    try:
+        dense = key(algo.match(hay, p))
+    finally:
+        gpu.set_option("dense_scores", 0)
+    assert first == sparse == dense and [q[0] for q in first] == [33 * sr, int(150.5 * sr)]
+
+
+def test_failed_certificate_redoes_only_that_chunk(gpu, oracle):
+    """The raw-score threshold adapts to the lowest chunk minimum seen with a needle.  A later
+    haystack with one chunk whose minimum lies far below it (an inverted copy of the needle:
+    score -1) fails that chunk's certificate; the chunk is redone in place and the result
+    equals both the oracle and a fresh handle's (dense) answer bit for bit."""
+    sr = 44100
+    s = 3 * sr
+    needle = oracle.synth_uniform(15, 0, 0, s)
+    calm = oracle.synth_uniform(15, 1, 0, 200 * sr)
+    calm[20 * sr:20 * sr + s] += needle
+    wild = oracle.synth_uniform(15, 2, 0, 200 * sr)
+    wild[70 * sr:70 * sr + s] -= needle                      # chunk 1: minimum ~ -1
+    wild[75 * sr:75 * sr + s] += needle                      # ... and a hit in the same chunk
+    wild[150 * sr:150 * sr + s] += needle
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=3.0, distance_s=2.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, wild, needle, p.chunk, p.overlap, 0.13, p.min_distance, 2.0)
+    assert [e[0] for e in exp] == [75 * sr, 150 * sr]
+    fresh = key(gpu.HipConvolve(needle).match(wild, p))
+    algo = gpu.HipConvolve(needle)
+    algo.match(calm, p)                                      # history: minimum ~ -0.03
+    got = algo.match(wild, p)                                # chunk 1 fails its certificate
+    assert key(got) == fresh
+    assert_same(got, exp)
+    # the same inside a batch (score buffers of the redone haystack were reused meanwhile)
+    algo2 = gpu.HipConvolve(needle)
+    algo2.match(calm, p)
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in (calm, wild, calm)]
+    res = algo2.match_batch_device([b.ptr for b in bufs], [calm.size] * 3, p)
+    assert key(res[1]) == fresh and [q.start for q in res[0]] == [20 * sr] == [q.start for q in res[2]]
+
+
+def test_more_peaks_than_a_header_holds_in_a_batch(gpu, oracle):
+    """Chunks with more than four peaks spill their list to the result arena instead of
+    forcing a second pass; in a batch every haystack still equals its single call."""
+    sr = 8000
+    needle = oracle.synth_uniform(19, 0, 0, sr // 2)
+    hays = []
+    for k in range(3):
+        h = oracle.synth_uniform(19, 1 + k, 0, 45 * sr)
+        for t in np.arange(1.0 + k, 44.0, 2.5):              # ~6 plants per 15 s chunk
+            off = int(t * sr)
+            h[off:off + needle.size] += needle
+        hays.append(h)
+    cfg = gpu.Config(chunk_size_s=15.0, overlap_length_s=0.5, distance_s=1.0, prominence=0.4)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in hays]
+    for _ in range(2):
+        res = algo.match_batch_device([b.ptr for b in bufs], [h.size for h in hays], p)
+        for r, h in zip(res, hays):
+            exp = oracle.calc_chunks(sr, h, needle, p.chunk, p.overlap, 0.4, p.min_distance, 1.0)
+            assert len(exp) >= 15
+            assert_same(r, exp)
+
+
+# ---------------------------------------------------------------------------
+# the pool: matcher::run's file loop sharded over devices (matcher/mod.rs:42-87)
+# ---------------------------------------------------------------------------
+def pool_inputs(oracle, sr):
+    needle = oracle.synth_uniform(23, 0, 0, 2 * sr)
+    secs = [40.0, 1.0, 95.0, 33.3, 61.0, 0.0, 12.0]
+    hays = []
+    for k, t in enumerate(secs):
+        h = oracle.synth_uniform(23, 10 + k, 0, int(t * sr))
+        if t > 10:
+            off = int(0.4 * t * sr) + 17 * k
+            h[off:off + needle.size] += needle
+        hays.append(h)
+    return needle, hays
+
+
+def test_pool_equals_single_device_calls(gpu, oracle):
+    sr = 22050
+    needle, hays = pool_inputs(oracle, sr)
+    cfg = gpu.Config(chunk_size_s=30.0, overlap_length_s=2.0, distance_s=10.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    singles = [key(algo.match(h, p)) if h.size else [] for h in hays]
+    assert [len(r) for r in singles] == [1, 0, 1, 1, 1, 0, 1]
+    for devices in ([0], [0, 0], [0, 0, 0]):              # several slots on one device share its queue
+        pool = gpu.Pool(needle, devices)
+        assert pool.size == len(devices) and pool.device_of(len(devices) - 1) == 0
+        for _ in range(2):
+            res = pool.match_batch(hays, p)               # host buffers: ring + copier thread per slot
+            assert [key(r) for r in res] == singles, devices
+        bufs = [gpu.DeviceBuffer.from_numpy(0, h) if h.size else None for h in hays]
+        res = pool.match_batch_device([b.ptr if b else None for b in bufs], [h.size for h in hays], p)
+        assert [key(r) for r in res] == singles, devices
+        assert pool.match_batch([], p) == []
+        pool.close()
+    every = gpu.Pool(needle)                               # devices = NULL: all visible devices
+    assert every.size == gpu.device_count()
+    assert [key(r) for r in every.match_batch(hays, p)] == singles
+
+
+def test_pool_progress_uses_batch_indices_and_capacity(gpu, oracle):
+    sr = 22050
+    needle, hays = pool_inputs(oracle, sr)
+    cfg = gpu.Config(chunk_size_s=30.0, overlap_length_s=2.0, distance_s=10.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    pool = gpu.Pool(needle, [0, 0])
+    ev = []
+    lock = threading.Lock()
+
+    def on(k, stage, n):
+        with lock:
+            ev.append((k, stage, n))
+    gpu.set_progress_callback(on)
+    try:
+        pool.match_batch(hays, p)
+    finally:
+        gpu.set_progress_callback(None)
+    active = [k for k, h in enumerate(hays) if h.size >= needle.size]
+    assert sorted(e[0] for e in ev if e[1] == 0) == active and sorted(e[0] for e in ev if e[1] == 1) == active
+    # a too small output capacity is reported, with the counts filled in
+    k = len(hays)
+    arr_p = (C.c_void_p * k)(*[h.ctypes.data if h.size else None for h in hays])
+    arr_l = (C.c_size_t * k)(*[h.size for h in hays])
+    counts = (C.c_size_t * k)()
+    rc = gpu.lib().am_pool_match_batch(pool._p, arr_p, arr_l, k, C.byref(p), None, 0, counts)
+    assert rc == gpu.AM_ERR_CAPACITY and list(counts) == [1, 0, 1, 1, 1, 0, 1]

@@ -7,10 +7,10 @@ cp $lib /tmp/keep.so
 for r in $(seq $rounds); do
   for v in audio-matcher_amd/build/variants/*.so; do
     cp $v $lib
-    python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --no-extra-legs --no-batch-1000 "$@" 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); k=d['roofline_pipeline']['kernel_ms_per_step']
-print('$v'.split('/')[-1], round(d['ms_per_step'],4), {a:round(b,4) for a,b in k.items()})"
+d=json.loads(sys.stdin.read()); k=d['roofline_pipeline']['kernel_ms_per_haystack']
+print('$v'.split('/')[-1], 'ms/haystack', round(d['ms_per_step']/d['config']['haystacks_per_rank_per_step'],4), {a:round(b,4) for a,b in k.items()})"
   done
 done
 cp /tmp/keep.so $lib

@@ -36,5 +36,8 @@ for g in groups:
         for _ in range(3):
             am.match_multi_device(algos, hay.ptr, h, p)
         kern = {n: round(prof.query(n)[0] / 3, 4) for n in KN}
-    out[f"group{g}"] = {"needle_samples_per_s": nn * h / dt, "ms_per_needle_hour": dt / nn * 1e3, "kernel_ms_per_call": kern}
+    rate = nn * h / dt
+    # (16 + 16 K) N bytes per block of N - S + 1 samples at K = 32, N = 2^22: 18.44 B per needle-sample
+    out[f"group{g}"] = {"needles": nn, "needle_samples_per_s": rate, "ms_per_needle_hour": dt / nn * 1e3,
+                        "survey_model_frac_of_8TBs": rate * 18.44 / 8e12, "kernel_ms_per_call": kern}
 print(json.dumps(out, indent=1))

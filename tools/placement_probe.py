@@ -9,8 +9,6 @@ sys.path.insert(0, "audio-matcher_amd/python"); sys.path.insert(0, "audio-matche
 import audiomatch_amd as am
 
 pad = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-if len(sys.argv) > 2:
-    am.set_option("vmm_work", int(sys.argv[2]))
 SR = 44100; s = 10 * SR; h = 3600 * SR
 dummy = am.DeviceBuffer(0, pad) if pad else None
 needle = am.synth_uniform_device(0, s, 1, 0)
@@ -31,4 +29,4 @@ with am.Profile(0) as prof:
     for _ in range(20):
         algo.match_device(hay.ptr, h, p)
     kern = {n: round(prof.query(n)[0] / 20, 4) for n in KN}
-print("vmm", sys.argv[2] if len(sys.argv) > 2 else 0, "pad %10d  hay %#x needle %#x  ms/step %.4f  %s" % (pad, hay.ptr, needle.ptr, dt * 1e3, kern))
+print("pad %10d  hay %#x needle %#x  ms/step %.4f  %s" % (pad, hay.ptr, needle.ptr, dt * 1e3, kern))
