@@ -195,3 +195,24 @@ def test_isa_has_no_store_data_hazard(tmp_path):
         files = list(ex.map(emit, am_build.SOURCES))
     found = [hit for f in files for hit in chk.check(f)]
     assert found == [], found[:3]
+    # the checker itself: every wide-store family is recognised, a safe distance is accepted
+    bad = {
+        "buffer_store_dwordx4 v[2:5], v1, s[0:3], s30 offen\n\tv_sub_f32 v4, v6, v7": [4],
+        "global_store_dwordx4 v[8:9], v[2:5], off nt\n\tv_mov_b32 v2, 0": [2],
+        "buffer_store_dwordx3 v[2:4], v1, s[0:3], 0 offen\n\ts_nop 0\n\tv_add_f32 v3, v3, v3": [3],
+        "tbuffer_store_format_xyzw v[10:13], v1, s[0:3], s4 format:77 offen\n\tv_mov_b32 v13, v0": [13],
+        "flat_store_dwordx4 v[0:1], v[20:23]\n\tv_fma_f32 v21, v1, v2, v3": [21],
+        "global_atomic_cmpswap_x2 v[0:1], v[4:7], off\n\tv_mov_b32 v5, 1": [5],
+    }
+    ok = ["buffer_store_dwordx4 v[2:5], v1, s[0:3], s30 offen\n\ts_nop 1\n\tv_sub_f32 v4, v6, v7",
+          "buffer_store_dwordx2 v[2:3], v1, s[0:3], s30 offen\n\tv_sub_f32 v2, v6, v7",
+          "global_store_dwordx4 v[8:9], v[2:5], off\n\tv_mov_b32 v8, 0"]
+    for i, (asm, regs_hit) in enumerate(bad.items()):
+        f = tmp_path / f"bad{i}.s"
+        f.write_text("kern:\n\t" + asm + "\n\ts_endpgm\n")
+        hits = chk.check(str(f))
+        assert len(hits) == 1 and hits[0][4] == regs_hit, (asm, hits)
+    for i, asm in enumerate(ok):
+        f = tmp_path / f"ok{i}.s"
+        f.write_text("kern:\n\t" + asm + "\n\ts_endpgm\n")
+        assert chk.check(str(f)) == [], asm

@@ -13,14 +13,19 @@ SGPR soffset: two wait states between the store and the overwrite (an instructio
 state, `s_nop N` counts N + 1).  The library's 16-byte buffer store helper adds `s_nop 1` itself.
 
 This script disassembles nothing itself: give it the .s files hipcc writes with
-`--cuda-device-only -S`.  It reports every >64-bit store whose data registers are written again with
+`--cuda-device-only -S`.  It reports every VMEM / FLAT instruction with more than 64 bits of store data (dwordx3/x4, typed and
+formatted xyz/xyzw stores, 128-bit compare-and-swap) whose data registers are written again with
 fewer than NEED wait states in between, in straight-line code.  Exit code 1 if any is found."""
 import re
 import sys
 
 WINDOW = 12
 NEED = 2
-STORE = re.compile(r"^\s*(buffer_store_dwordx[34]|global_store_dwordx[34]|flat_store_dwordx[34]|scratch_store_dwordx[34])\s+(.*)$")
+# every VMEM / FLAT instruction whose store data is wider than 64 bits: plain, typed and
+# formatted stores, and the 128-bit compare-and-swap atomics (data = two 64-bit values)
+WIDE = r"(?:dwordx[34]|format_xyzw?|format_d16_hi_xyzw?|b96|b128)"
+STORE = re.compile(r"^\s*((?:buffer|tbuffer|global|flat|scratch)_store_" + WIDE +
+                   r"|(?:buffer|global|flat)_atomic_cmpswap_x2)\s+(.*)$")
 VREG = re.compile(r"v\[(\d+):(\d+)\]|v(\d+)")
 
 
@@ -61,9 +66,13 @@ def check(path):
         if not m:
             continue
         ops = m.group(2).split(",")
-        data = regs(ops[1] if m.group(1).startswith(("global", "flat", "scratch")) else ops[0])
-        if m.group(1).startswith("scratch"):
-            data = regs(ops[1]) if len(ops) > 1 else set()
+        # operand order: buffer/tbuffer: vdata first; global/flat/scratch: address first, then vdata
+        # (a returning atomic has its destination in front of both)
+        first_is_data = m.group(1).startswith(("buffer", "tbuffer"))
+        idx = 0 if first_is_data else 1
+        if "atomic" in m.group(1) and re.search(r"\b(sc0|glc)\b", t):
+            idx += 1
+        data = regs(ops[idx]) if len(ops) > idx else set()
         waits = 0
         for j in range(i + 1, min(i + 1 + WINDOW, len(body))):
             k2, t2 = body[j]
