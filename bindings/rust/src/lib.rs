@@ -57,6 +57,20 @@ extern "C" {
         h: *const AmNeedle, interleaved: *const i16, frames: usize, p: *const AmMatchParams,
         out: *mut AmPeak, cap: usize, n_out: *mut usize,
     ) -> c_int;
+    /// haystack k -> shard k mod n_shards (no device needed)
+    pub fn am_shard_plan(n_items: usize, n_shards: usize, shard: usize, first: *mut usize, stride: *mut usize, count: *mut usize) -> c_int;
+    /// the file loop of matcher::run (matcher/mod.rs:42-87) over every GPU of the node
+    pub fn am_pool_create(needle: *const f32, n: usize, devices: *const c_int, n_dev: usize, out: *mut *mut AmPool) -> c_int;
+    pub fn am_pool_destroy(pool: *mut AmPool);
+    pub fn am_pool_match_batch(
+        pool: *mut AmPool, haystacks: *const *const f32, lens: *const usize, n_hay: usize,
+        p: *const AmMatchParams, out: *mut AmPeak, cap_per_hay: usize, n_out: *mut usize,
+    ) -> c_int;
+}
+
+#[repr(C)]
+pub struct AmPool {
+    _private: [u8; 0],
 }
 
 /// audio_matcher.rs:55-59

@@ -15,6 +15,7 @@
 // forwarded to libaudiomatch_amd.so (include/audiomatch.h); there is no CPU path.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -106,6 +107,8 @@ public:
         return out;
     }
     const am_needle* handle() const { return h_; }
+    // per-handle "log_n" / "half_pipeline" (-1 = follow the process default)
+    void set_option(const char* key, long long value) { check(am_needle_set_option(h_, key, value)); }
 
 private:
     am_needle* h_ = nullptr;
@@ -130,5 +133,51 @@ inline std::vector<Peak> calc_chunks(std::uint16_t sr, const float* m_samples, s
                       buf[i].height, buf[i].prominence};
     return out;
 }
+
+// The per-file loop of matcher::run (matcher/mod.rs:42-87) over every GPU of the node: the
+// needle replicated per device, haystack k matched on device k mod n (am_pool_*), one submit
+// thread per device inside the library, results gathered on the host.
+class HipConvolvePool {
+public:
+    // devices empty: every visible device
+    explicit HipConvolvePool(const std::vector<float>& sample_data, const std::vector<int>& devices = {}) {
+        check(am_pool_create(sample_data.data(), sample_data.size(), devices.empty() ? nullptr : devices.data(),
+                             devices.size(), &p_));
+    }
+    HipConvolvePool(const HipConvolvePool&) = delete;
+    HipConvolvePool& operator=(const HipConvolvePool&) = delete;
+    ~HipConvolvePool() { am_pool_destroy(p_); }
+    std::size_t size() const {
+        std::size_t n = 0;
+        check(am_pool_size(p_, &n));
+        return n;
+    }
+    // calc_chunks for every haystack of the batch (host buffers); result k belongs to haystacks[k]
+    std::vector<std::vector<Peak>> calc_chunks(std::uint16_t sr, const std::vector<const float*>& haystacks,
+                                               const std::vector<std::size_t>& lens, bool scale, const Config& config,
+                                               std::size_t cap_per_haystack = 256) {
+        const am_match_params p = config.params(sr, scale);
+        const std::size_t k = haystacks.size();
+        std::vector<am_peak> buf(k * cap_per_haystack);
+        std::vector<std::size_t> n(k, 0);
+        int rc = am_pool_match_batch(p_, haystacks.data(), lens.data(), k, &p, buf.data(), cap_per_haystack, n.data());
+        if (rc == AM_ERR_CAPACITY) {
+            for (std::size_t v : n) cap_per_haystack = std::max(cap_per_haystack, v);
+            buf.assign(k * cap_per_haystack, am_peak{});
+            rc = am_pool_match_batch(p_, haystacks.data(), lens.data(), k, &p, buf.data(), cap_per_haystack, n.data());
+        }
+        check(rc);
+        std::vector<std::vector<Peak>> out(k);
+        for (std::size_t i = 0; i < k; ++i)
+            for (std::size_t j = 0; j < n[i]; ++j) {
+                const am_peak& q = buf[i * cap_per_haystack + j];
+                out[i].push_back(Peak{static_cast<std::size_t>(q.start), static_cast<std::size_t>(q.end), q.height, q.prominence});
+            }
+        return out;
+    }
+
+private:
+    am_pool* p_ = nullptr;
+};
 
 }  // namespace audiomatch
