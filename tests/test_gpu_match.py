@@ -355,8 +355,10 @@ def test_error_codes(gpu):
     assert rc == gpu.AM_ERR_CAPACITY and n.value == 93
     assert L.am_correlate(algo._h, x.ctypes.data, x.size, 7, 0, out, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
     assert L.am_correlate(None, x.ctypes.data, x.size, 2, 0, out, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
-    p = gpu.Config().params(8000, gpu.Scale.MY)
+    p = gpu.Config().params(8000, gpu.Scale.MY)     # any CorrelateAlgo's scaling rides calc_chunks (audio_matcher.rs:88-97)
     buf = (gpu.AmPeak * 4)()
+    assert L.am_match(algo._h, x.ctypes.data, x.size, C.byref(p), buf, 4, C.byref(n)) == 0
+    p.scale = 3
     assert L.am_match(algo._h, x.ctypes.data, x.size, C.byref(p), buf, 4, C.byref(n)) == gpu.AM_ERR_INVALID_ARG
     p = gpu.Config().params(8000, gpu.Scale.LIB)
     p.chunk = 0
