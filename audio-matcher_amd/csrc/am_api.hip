@@ -130,7 +130,7 @@ struct Ctx {
     hipStream_t stream2 = nullptr;           // peak pick of haystack k beside the transforms of k+1 (batches)
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur;
+    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur, wide_ctl, wide_list;
     // second set of the score-side buffers: in a batch the peak pick of haystack k runs on
     // stream2 beside the transforms of haystack k+1, which then need their own set
     DevBuf scores_b, stats_b, stats32_b, wflags_b, peaks_b;
@@ -556,11 +556,20 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         if (d_stats32) AM_HIP(launch_stats_reduce(st, d_stats32, n_scores, (float2*)bstats.p));
         else AM_HIP(launch_tile_stats(st, d_scores, n_scores, (float2*)bstats.p));
     }
+    // hand-over area for chunks with many candidate tiles (per chunk of this launch; the picks
+    // of one call run in stream order, so one area serves them all)
+    if ((rc = c->wide_ctl.ensure((size_t)nsegs * 12))) return rc;
+    if ((rc = c->wide_list.ensure((size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    WideState wide{};
+    wide.state = static_cast<int*>(c->wide_ctl.p);
+    wide.count = reinterpret_cast<unsigned*>(wide.state + nsegs);
+    wide.seg_min = reinterpret_cast<float*>(wide.state + 2 * nsegs);
+    wide.list = static_cast<am_peak*>(c->wide_list.p);
     {
         ProfScope ps(c, KN_PEAKS, st);
         AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena));
+                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide));
     }
     return AM_OK;
 }
@@ -1333,7 +1342,7 @@ int am_shutdown(void) {
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
                           &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b,
-                          &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur})
+                          &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur, &c->wide_ctl, &c->wide_list})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
         if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }

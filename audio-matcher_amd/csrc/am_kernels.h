@@ -109,9 +109,19 @@ struct SparseScores {
     int hop, log_n2;
     double inv_hop;
 };
+// Hand-over of chunks with many candidate tiles from peaks_kernel to peaks_wide /
+// peaks_finish (device memory, one entry per chunk of the launch; list: AM_MAX_PEAKS_PER_CHUNK
+// entries per chunk).  list == nullptr: every chunk is finished by its one workgroup.
+struct WideState {
+    int* state;          // 0 = finished by peaks_kernel, 1 = handed over
+    unsigned* count;     // peaks appended to the chunk's list (> AM_MAX_PEAKS_PER_CHUNK: overflow)
+    float* seg_min;
+    am_peak* list;
+};
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena);
+                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
+                        const WideState& wide);
 // writes sumsq_parts(n) partial sums (one per workgroup) to d_parts
 int sumsq_parts(long long n);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts);

@@ -277,10 +277,160 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
     return prom >= min_prom;
 }
 
+// ---------------------------------------------------------------------------
+// One piece of a chunk (a full 1024-score tile, or the raw head / tail piece): local
+// maxima with flat tops whose height can qualify, then their prominence.
+//
+// The piece and a halo of kHalo scores on either side are staged in LDS first (as
+// score_for_min sees them: raw where written, the run's exact minimum elsewhere).  Every
+// thread that finds a maximum then looks outwards through that window by itself:
+//   * a strictly higher score before the running minimum has dropped by min_prom settles
+//     that side against the candidate (prominence = h - max(lmin, rmin) < min_prom): rejected
+//     without a walk -- this is what almost every maximum of an oscillating score array is;
+//   * both sides settled (higher score or chunk edge inside the window): accepted with its
+//     exact prominence, again without a walk;
+//   * otherwise the candidate is queued for the wave-cooperative walk (prominence()).
+// The arithmetic is the walk's own (same minima over the same scores, same comparisons), so
+// the outcome is bit-identical to walking every candidate.
+constexpr int kHalo = 256;
+constexpr int kWin = kTile + 2 * kHalo;
+
+struct ChunkView {
+    const float* g;
+    const float2* stats;
+    SparseScores sp;
+    long long a, b;
+    float seg_min, min_prom;
+};
+
+// scan from `from` in direction `step` until (exclusive) w_end; returns true when the side is
+// settled (a strictly higher score was met, or w_end is the chunk edge c_end)
+__device__ __forceinline__ bool side_scan(const float* win, long long win_lo, long long from, long long step,
+                                          long long w_end, long long c_end, float h, float& mn) {
+    for (long long j = from; j != w_end; j += step) {
+        const float v = win[j - win_lo];
+        if (v > h) return true;
+        mn = fminf(mn, v);
+    }
+    return w_end == c_end;
+}
+
+template <class Emit>
+__device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, float* win, Cand* queue, int* queue_n,
+                           int* overflow, int tid, Emit emit) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const long long a = cv.a, b = cv.b;
+    // window [w_lo, w_hi) = piece + halo, clipped to the chunk
+    const long long w_lo = lo - kHalo > a ? lo - kHalo : a;
+    const long long w_hi = hi + kHalo < b ? hi + kHalo : b;
+    for (long long i = w_lo + tid; i < w_hi; i += kPeakThreads) win[i - w_lo] = score_for_min(cv.g, cv.sp, i);
+    __syncthreads();
+    for (long long i = lo + tid; i < hi; i += kPeakThreads) {
+        if (i <= a || i >= b - 1) continue;
+        const float x = win[i - w_lo];
+        // (an unwritten score shows its run's minimum here, which is below theta and therefore
+        // fails this test whenever the chunk's certificate holds)
+        if (!((x - cv.seg_min) >= cv.min_prom) || !(win[i - 1 - w_lo] < x)) continue;
+        long long k = i + 1;
+        while (k < b - 1 && (k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) == x) ++k;
+        if (!((k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) < x)) continue;
+        // flat-topped maximum [i, k) of height x: settle it inside the window if possible
+        float lmn = x, rmn = x;
+        const bool dl = side_scan(win, w_lo, i - 1, -1, w_lo - 1, a - 1, x, lmn);
+        if (dl && !((x - lmn) >= cv.min_prom)) continue;
+        const bool dr = k <= w_hi && side_scan(win, w_lo, k, 1, w_hi, b, x, rmn);
+        if (dr && !((x - rmn) >= cv.min_prom)) continue;
+        if (dl && dr) {
+            emit((long long)i, k, x, x - fmaxf(lmn, rmn));
+            continue;
+        }
+        const int slot = atomicAdd(queue_n, 1);
+        if (slot < kQueueCap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
+        else *overflow = 1;
+    }
+    __syncthreads();
+    const int qn = *queue_n < kQueueCap ? *queue_n : kQueueCap;
+    // -- prominence by walking, one wavefront per remaining candidate --
+    for (int q = wv; q < qn; q += kWaves) {
+        const Cand cd = queue[q];
+        float prom = 0.0f;
+        const bool keep = prominence(cv.g, cv.stats, cv.sp, a, b, cd.ps, cd.pe, cd.h, cv.min_prom, lane, prom);
+        if (keep && lane == 0) emit(cd.ps, cd.pe, cd.h, prom);
+    }
+    __syncthreads();
+    if (tid == 0) *queue_n = 0;
+    __syncthreads();
+}
+
+// The end of find_peaks for one chunk: `rn` peaks that passed the prominence filter sit in
+// res[]; order them by height descending (ties: position ascending), apply the greedy
+// min_distance filter, write the result header, the chunk's output list and, for lists
+// longer than a header holds, the spill arena.
+__device__ void finish_chunk(am_peak* res, int rn, int* order, int overflow, long long min_dist, float seg_min,
+                             am_peak* my_out, SegHeader* hd, const PeakArena& arena, int* kept_s, int* spill_off_s, int tid) {
+    for (int i = tid; i < rn; i += kPeakThreads) {
+        const float hi_ = res[i].height; const uint64_t si = res[i].start;
+        int rank = 0;
+        for (int j = 0; j < rn; ++j) {
+            const float hj = res[j].height;
+            if (hj > hi_ || (hj == hi_ && res[j].start < si)) ++rank;
+        }
+        order[rank] = i;
+    }
+    __syncthreads();
+    // ---- min_distance: greedy by descending height (serial, rn is small) ----
+    if (tid == 0) {
+        int kept = 0;
+        for (int r = 0; r < rn; ++r) {
+            const am_peak pk = res[order[r]];
+            const long long mid = (long long)((pk.start + pk.end) / 2);
+            bool ok = true;
+            if (min_dist > 0) {
+                for (int k = 0; k < kept && ok; ++k) {
+                    const long long mk = (long long)((my_out[k].start + my_out[k].end) / 2);
+                    const long long d = mid > mk ? mid - mk : mk - mid;
+                    if (d < min_dist) ok = false;
+                }
+            }
+            if (ok) {
+                if (kept < kInlinePeaks) hd->first[kept] = pk;
+                my_out[kept++] = pk;
+            }
+        }
+        // a list longer than the header holds goes to the spill arena as a whole
+        int off = -1, ovf = overflow;
+        if (kept > kInlinePeaks && arena.base != nullptr) {
+            const unsigned o = atomicAdd(arena.cursor, (unsigned)kept);
+            if (o + (unsigned)kept <= arena.cap) off = (int)o;
+            else ovf |= 4;
+        }
+        *kept_s = kept; *spill_off_s = off;
+        hd->n = kept;
+        hd->overflow = ovf;
+        hd->seg_min = seg_min;
+        hd->arena_off = off;
+    }
+    __syncthreads();
+    if (*spill_off_s >= 0) {
+        __threadfence_block();   // thread 0's my_out stores are visible to the block (same CU)
+        for (int i = tid; i < *kept_s; i += kPeakThreads) arena.base[*spill_off_s + i] = my_out[i];
+    }
+}
+
+// Chunks whose general path would visit more than kWideTiles candidate tiles are not
+// finished by their one workgroup: peaks_kernel marks them in `wide` and the two kernels
+// behind it take over -- peaks_wide spreads a chunk's pieces over kWideParts workgroups that
+// append the peaks passing the prominence filter to the chunk's list, peaks_finish sorts and
+// filters that list.  (A score array that is not white -- speech or music against a jingle --
+// has thousands of candidate maxima per chunk; one workgroup per chunk would leave 196 of
+// the 256 CUs idle for tens of milliseconds.)
+constexpr int kWideTiles = 48;
+constexpr int kWideParts = 16;
+
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
-             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena) {
+             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -292,12 +442,13 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ int cand_tiles[kCandCap];
     __shared__ int cand_n;
     __shared__ int kept_s, spill_off_s;
+    __shared__ float win[kWin];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Segment sg = segs[blockIdx.x];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
-    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; }
+    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; wide.state[blockIdx.x] = 0; }
     if (b - a < 3) {
         if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = 0.f; hdr[blockIdx.x].arena_off = -1; }
         return;
@@ -322,7 +473,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     const float seg_min = seg_min_s;
     // Sparse raw scores are sufficient only if every score that can qualify
     // (x - seg_min >= min_prom) was written (x >= theta); otherwise report it and
-    // let the host redo this haystack with theta = -inf.
+    // let the host redo this chunk with theta = -inf.
     if (sp.wflags != nullptr && !((sp.theta - seg_min) < min_prom)) {
         if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
         return;
@@ -420,9 +571,22 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         }
     }
     __syncthreads();
+    if (cand_n > kWideTiles && wide.list != nullptr) {
+        // too much for one workgroup: hand the chunk to peaks_wide / peaks_finish
+        if (tid == 0) { wide.seg_min[blockIdx.x] = seg_min; wide.count[blockIdx.x] = 0; wide.state[blockIdx.x] = 1; }
+        return;
+    }
     // more candidates than the list holds: visit every full tile instead
     const bool all_tiles = cand_n > kCandCap;
     const long long nmid = has_full ? (all_tiles ? (tl - tf) : cand_n) : 0;
+    ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
+    auto emit = [&](long long ps, long long pe, float h, float prom) {
+        const int slot = atomicAdd(&res_n, 1);
+        if (slot < AM_MAX_PEAKS_PER_CHUNK) {
+            res[slot].start = (uint64_t)ps; res[slot].end = (uint64_t)pe;
+            res[slot].height = h; res[slot].prominence = prom;
+        } else overflow = 1;
+    };
     // ---- pieces: head, candidate tiles, tail --------------------------------
     const long long npieces = nmid + 2;
     for (long long pc = 0; pc < npieces; ++pc) {
@@ -435,89 +599,69 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
             if (all_tiles && !((stats[t].y - seg_min) >= min_prom)) continue;
         }
         if (hi <= lo) continue;
-        // -- local maxima with flat tops whose height can qualify --
-        for (long long i = lo + tid; i < hi; i += kPeakThreads) {
-            if (i <= a || i >= b - 1) continue;
-            if (!run_written(sp, i)) continue;   // every score there is < theta: cannot qualify
-            const float x = g[i];
-            if (!((x - seg_min) >= min_prom) || !(score_for_cmp(g, sp, i - 1) < x)) continue;
-            long long k = i + 1;
-            while (k < b - 1 && score_for_cmp(g, sp, k) == x) ++k;
-            if (score_for_cmp(g, sp, k) < x) {
-                const int slot = atomicAdd(&queue_n, 1);
-                if (slot < kQueueCap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
-                else overflow = 1;
-            }
-        }
-        __syncthreads();
-        const int qn = queue_n < kQueueCap ? queue_n : kQueueCap;
-        // -- prominence, one wavefront per candidate --
-        for (int q = wv; q < qn; q += kWaves) {
-            const Cand cd = queue[q];
-            float prom = 0.0f;
-            const bool keep = prominence(g, stats, sp, a, b, cd.ps, cd.pe, cd.h, min_prom, lane, prom);
-            if (keep && lane == 0) {
-                const int slot = atomicAdd(&res_n, 1);
-                if (slot < AM_MAX_PEAKS_PER_CHUNK) {
-                    res[slot].start = (uint64_t)cd.ps; res[slot].end = (uint64_t)cd.pe;
-                    res[slot].height = cd.h; res[slot].prominence = prom;
-                } else overflow = 1;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) queue_n = 0;
-        __syncthreads();
+        scan_piece(cv, lo, hi, win, queue, &queue_n, &overflow, tid, emit);
     }
-
-    // ---- order by height descending (ties: position ascending) -------------
     const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
-    for (int i = tid; i < rn; i += kPeakThreads) {
-        const float hi_ = res[i].height; const uint64_t si = res[i].start;
-        int rank = 0;
-        for (int j = 0; j < rn; ++j) {
-            const float hj = res[j].height;
-            if (hj > hi_ || (hj == hi_ && res[j].start < si)) ++rank;
-        }
-        order[rank] = i;
-    }
+    finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid);
+}
+
+// grid (kWideParts, nsegs): part p of chunk s takes the head piece (p == 0), the tail piece
+// (p == 1 mod parts) and every kWideParts-th full tile, and appends what passes the
+// prominence filter to the chunk's list.
+__global__ void __launch_bounds__(kPeakThreads)
+peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
+           const Segment* __restrict__ segs, float min_prom, SparseScores sp, WideState wide) {
+    __shared__ Cand queue[kQueueCap];
+    __shared__ int queue_n;
+    __shared__ int overflow;
+    __shared__ float win[kWin];
+    const int seg = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    if (wide.state[seg] != 1) return;
+    const Segment sg = segs[seg];
+    const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
+    const long long tf = (a + kTile - 1) / kTile;
+    const long long tl = b / kTile;
+    const bool has_full = tl > tf;
+    const long long head_hi = has_full ? tf * kTile : b;
+    const long long tail_lo = has_full ? tl * kTile : b;
+    const float seg_min = wide.seg_min[seg];
+    if (tid == 0) { queue_n = 0; overflow = 0; }
     __syncthreads();
-    // ---- min_distance: greedy by descending height (serial, rn is small) ----
-    if (tid == 0) {
-        int kept = 0;
-        for (int r = 0; r < rn; ++r) {
-            const am_peak pk = res[order[r]];
-            const long long mid = (long long)((pk.start + pk.end) / 2);
-            bool ok = true;
-            if (min_dist > 0) {
-                for (int k = 0; k < kept && ok; ++k) {
-                    const long long mk = (long long)((my_out[k].start + my_out[k].end) / 2);
-                    const long long d = mid > mk ? mid - mk : mk - mid;
-                    if (d < min_dist) ok = false;
-                }
-            }
-            if (ok) {
-                if (kept < kInlinePeaks) hdr[blockIdx.x].first[kept] = pk;
-                my_out[kept++] = pk;
-            }
+    ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
+    am_peak* list = wide.list + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
+    auto emit = [&](long long ps, long long pe, float h, float prom) {
+        const unsigned slot = atomicAdd(&wide.count[seg], 1u);
+        if (slot < (unsigned)AM_MAX_PEAKS_PER_CHUNK) {
+            am_peak pk; pk.start = (uint64_t)ps; pk.end = (uint64_t)pe; pk.height = h; pk.prominence = prom;
+            list[slot] = pk;
         }
-        // a list longer than the header holds goes to the spill arena as a whole
-        int off = -1, ovf = overflow;
-        if (kept > kInlinePeaks && arena.base != nullptr) {
-            const unsigned o = atomicAdd(arena.cursor, (unsigned)kept);
-            if (o + (unsigned)kept <= arena.cap) off = (int)o;
-            else ovf |= 4;
+    };
+    if (part == 0 && head_hi > a) scan_piece(cv, a, head_hi, win, queue, &queue_n, &overflow, tid, emit);
+    if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, queue, &queue_n, &overflow, tid, emit);
+    if (has_full)
+        for (long long t = tf + part; t < tl; t += kWideParts) {
+            if (!((stats[t].y - seg_min) >= min_prom)) continue;
+            scan_piece(cv, t * kTile, (t + 1) * kTile, win, queue, &queue_n, &overflow, tid, emit);
         }
-        kept_s = kept; spill_off_s = off;
-        hdr[blockIdx.x].n = kept;
-        hdr[blockIdx.x].overflow = ovf;
-        hdr[blockIdx.x].seg_min = seg_min;
-        hdr[blockIdx.x].arena_off = off;
-    }
+    if (tid == 0 && overflow) atomicAdd(&wide.count[seg], (unsigned)AM_MAX_PEAKS_PER_CHUNK + 1u);   // poisons the count: reported as overflow
+}
+
+// grid nsegs: sort + distance filter of a chunk that went through peaks_wide
+__global__ void __launch_bounds__(kPeakThreads)
+peaks_finish(const Segment* __restrict__ segs, long long min_dist, am_peak* __restrict__ out,
+             SegHeader* __restrict__ hdr, PeakArena arena, WideState wide) {
+    __shared__ am_peak res[AM_MAX_PEAKS_PER_CHUNK];
+    __shared__ int order[AM_MAX_PEAKS_PER_CHUNK];
+    __shared__ int kept_s, spill_off_s;
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    if (wide.state[seg] != 1) return;
+    const unsigned cnt = wide.count[seg];
+    const int rn = cnt < (unsigned)AM_MAX_PEAKS_PER_CHUNK ? (int)cnt : AM_MAX_PEAKS_PER_CHUNK;
+    const am_peak* list = wide.list + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
+    for (int i = tid; i < rn; i += kPeakThreads) res[i] = list[i];
     __syncthreads();
-    if (spill_off_s >= 0) {
-        __threadfence_block();   // thread 0's my_out stores are visible to the block (same CU, L1-coherent within it)
-        for (int i = tid; i < kept_s; i += kPeakThreads) arena.base[spill_off_s + i] = my_out[i];
-    }
+    finish_chunk(res, rn, order, cnt > (unsigned)AM_MAX_PEAKS_PER_CHUNK ? 1 : 0, min_dist, wide.seg_min[seg],
+                 out + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK, &hdr[seg], arena, &kept_s, &spill_off_s, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -598,10 +742,17 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
-                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena) {
+                        am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
+                        const WideState& wide) {
     if (nsegs <= 0) return hipSuccess;
     hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_hdr, sp, arena);
+                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide);
+    if (wide.list != nullptr) {
+        // both return at once for chunks that peaks_kernel finished itself (the usual case)
+        hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
+                           min_prom, sp, wide);
+        hipLaunchKernelGGL(peaks_finish, dim3(nsegs), dim3(kPeakThreads), 0, st, d_segs, min_dist, d_out, d_hdr, arena, wide);
+    }
     return hipGetLastError();
 }
 

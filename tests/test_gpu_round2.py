@@ -392,3 +392,60 @@ def test_pool_progress_uses_batch_indices_and_capacity(gpu, oracle):
     counts = (C.c_size_t * k)()
     rc = gpu.lib().am_pool_match_batch(pool._p, arr_p, arr_l, k, C.byref(p), None, 0, counts)
     assert rc == gpu.AM_ERR_CAPACITY and list(counts) == [1, 0, 1, 1, 1, 0, 1]
+
+
+# ---------------------------------------------------------------------------
+# score arrays that are not white: thousands of candidate maxima per chunk
+# ---------------------------------------------------------------------------
+def drifting_case(oracle, sr, seed):
+    """Needle with a DC offset and a 50 Hz tone, haystack with the same tone and a slow drift:
+    the scores drift by about +-0.13 (monotone inside a chunk) with a +-0.03 ripple on top."""
+    rng = np.random.default_rng(seed)
+    s, h = 2 * sr, 200 * sr
+    t = np.arange(h, dtype=np.float64)
+    tone = (0.0437 * np.sin(2 * np.pi * 50.0 / sr * t)).astype(np.float32)
+    drift = (0.04 * np.sin(2 * np.pi * t / (80.0 * sr))).astype(np.float32)
+    needle = rng.uniform(-0.25, 0.25, s).astype(np.float32) + tone[:s] + np.float32(0.1)
+    hay = rng.uniform(-0.25, 0.25, h).astype(np.float32) + tone + drift
+    plants = [int(13.3 * sr), int(95.0 * sr) + 7, int(171.2 * sr)]
+    for p0 in plants:
+        hay[p0:p0 + s] += needle
+    return needle, hay, plants
+
+
+def test_many_candidate_maxima_default_distance(gpu, oracle):
+    """Chunks with hundreds of candidate tiles (the multi-workgroup peak pick) and the
+    reference's default regime min_distance >= chunk: equal to the oracle, on the dense and the
+    sparse score path; only the planted hits qualify."""
+    sr = 8000
+    needle, hay, plants = drifting_case(oracle, sr, 31)
+    cfg = gpu.Config(chunk_size_s=20.0, overlap_length_s=2.0, distance_s=480.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 480.0)
+    assert [e[0] for e in exp] == [plants[0]]            # 480 s apart: the tallest overshadows the other two
+    cfg2 = gpu.Config(chunk_size_s=20.0, overlap_length_s=2.0, distance_s=30.0, prominence=0.13)
+    p2 = cfg2.params(sr, gpu.Scale.LIB)
+    exp2 = oracle.calc_chunks(sr, hay, needle, p2.chunk, p2.overlap, 0.13, p2.min_distance, 30.0)
+    assert [e[0] for e in exp2] == plants
+    algo = gpu.HipConvolve(needle)
+    for _ in range(2):
+        assert_same(algo.match(hay, p), exp)
+        assert_same(algo.match(hay, p2), exp2)
+
+
+def test_many_qualifying_maxima_small_distance(gpu, oracle):
+    """A low prominence threshold lets every ripple maximum qualify (hundreds per chunk) and
+    a short min_distance keeps dozens of them: the window test accepts most without a walk,
+    the chunk's pieces are spread over several workgroups, the list is sorted and filtered
+    afterwards -- all of it must equal the oracle peak for peak."""
+    sr = 8000
+    needle, hay, plants = drifting_case(oracle, sr, 37)
+    for chunk_s, dist_s, prom in ((10.0, 1.0, 0.04), (10.0, 0.0, 0.05), (25.0, 3.0, 0.045)):
+        cfg = gpu.Config(chunk_size_s=chunk_s, overlap_length_s=2.0, distance_s=dist_s, prominence=prom)
+        p = cfg.params(sr, gpu.Scale.LIB)
+        exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, prom, p.min_distance, dist_s, cap=1 << 16)
+        assert len(exp) > 30
+        algo = gpu.HipConvolve(needle)
+        for _ in range(2):
+            got = algo.match(hay, p, cap=1 << 16)
+            assert_same(got, exp)
