@@ -163,7 +163,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 #define AM_K1_STORE_NT 0
 #endif
 #ifndef AM_K3_LOAD_NT
-#define AM_K3_LOAD_NT 0
+#define AM_K3_LOAD_NT 1   // K3's once-read column loads: 0.180 -> 0.156 ms per 1 h haystack (profiles/r02/nt_ab.txt)
 #endif
 #ifndef AM_K1_LOAD_NT
 #define AM_K1_LOAD_NT 0

@@ -188,7 +188,7 @@ def test_calc_chunks_with_my_scaling(gpu, oracle):
         off = int(t * sr)
         hay[off:off + s] += needle
     window = 25 * sr
-    prom = 0.13 / window                                     # the usual threshold in MyConvolve's units
+    prom = 0.3 / window                                      # a threshold in MyConvolve's units (0.12 for the 10 s tail window)
     p = gpu.AmMatchParams(sr=sr, chunk=20 * sr, overlap=5 * sr, min_prominence=prom, min_distance=0,
                           overshadow_distance_s=4.0, scale=int(gpu.Scale.MY))
     exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, prom, 0, 4.0, scale=oracle.SCALE_MY)
@@ -202,8 +202,8 @@ def test_calc_chunks_with_my_scaling(gpu, oracle):
             assert abs(g.height - e[2]) < 1e-4 * e[2] and abs(g.prominence - e[3]) < 1e-4 * e[3]
     # a haystack shorter than one window: only a "tail" window exists
     short = hay[: 12 * sr]
-    exp = oracle.calc_chunks(sr, short, needle, p.chunk, p.overlap, 0.13 / (12 * sr), 0, 4.0, scale=oracle.SCALE_MY)
-    p.min_prominence = 0.13 / (12 * sr)
+    exp = oracle.calc_chunks(sr, short, needle, p.chunk, p.overlap, 0.3 / (12 * sr), 0, 4.0, scale=oracle.SCALE_MY)
+    p.min_prominence = 0.3 / (12 * sr)
     got = algo.match(short, p)
     assert [g.start for g in got] == [e[0] for e in exp] == [5 * sr]
     assert abs(got[0].height - exp[0][2]) < 1e-4 * exp[0][2]
@@ -440,7 +440,7 @@ def test_many_qualifying_maxima_small_distance(gpu, oracle):
     afterwards -- all of it must equal the oracle peak for peak."""
     sr = 8000
     needle, hay, plants = drifting_case(oracle, sr, 37)
-    for chunk_s, dist_s, prom in ((10.0, 1.0, 0.04), (10.0, 0.0, 0.05), (25.0, 3.0, 0.045)):
+    for chunk_s, dist_s, prom in ((10.0, 1.0, 0.04), (10.0, 0.0, 0.05), (15.0, 3.0, 0.045)):
         cfg = gpu.Config(chunk_size_s=chunk_s, overlap_length_s=2.0, distance_s=dist_s, prominence=prom)
         p = cfg.params(sr, gpu.Scale.LIB)
         exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, prom, p.min_distance, dist_s, cap=1 << 16)
