@@ -7,13 +7,14 @@ out=${1:-gpurun_out/prof}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 bench.py --no-cpu-baseline > "$out/stats.log" 2>&1 || exit 1
+lean="--no-cpu-baseline --no-extra-legs --no-batch-1000"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 bench.py $lean > "$out/stats.log" 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$out/pmc/$c" -o run -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --ramp-steps 0 > "$out/pmc_$c.log" 2>&1 || exit 1
+  rocprofv3 --pmc $c --output-format csv -d "$out/pmc/$c" -o run -- python3 bench.py $lean --steps 1 --warmup 1 --ramp-steps 0 --haystacks-per-step 3 > "$out/pmc_$c.log" 2>&1 || exit 1
 done
 python3 tools/pmc_summary.py "$out/pmc" "$out/pmc_traffic.json" > "$out/pmc_summary.log" 2>&1
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
+rm -rf "$out/stats" "$out/pmc"
 python3 tools/extra_bench.py > "$out/extra.json" 2> "$out/extra.err"
-python3 tools/multi_bench.py 8 1,4,8 > "$out/multi.json" 2> "$out/multi.err"
-python3 tools/batch_bench.py 16 > "$out/batch.json" 2> "$out/batch.err"
+python3 tools/multi_bench.py 32 8 > "$out/multi32.json" 2> "$out/multi32.err"
 echo collected

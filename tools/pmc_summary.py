@@ -33,7 +33,7 @@ def main():
     root, out = sys.argv[1], sys.argv[2]
     fetch = load(f"{root}/FETCH_SIZE", "FETCH_SIZE")
     write = load(f"{root}/WRITE_SIZE", "WRITE_SIZE")
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1",
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --haystacks-per-step 3 (per full-size launch)",
            "corrections": "KiB -> bytes (x1024); FETCH_SIZE x2 for 16-B-per-lane streaming reads (gfx950)",
            "kernels": {}}
     for key, pat in KEYS.items():
