@@ -69,10 +69,9 @@ static std::atomic<long long> g_opt_profile_mask{-1};    // bit i = bracket kern
 static std::atomic<long long> g_opt_half{0};             // 1 = half-precision storage of the work matrix (config 5)
 static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
 static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
-static std::atomic<long long> g_opt_k2_oop{0};           // 1 = K2 writes its rows to a second work matrix instead of in place
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
 struct Opts {
-    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, k2_oop;
+    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense;
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
@@ -293,7 +292,6 @@ static Opts snapshot_opts(const am_needle* h) {
     o.batch_overlap = g_opt_batch_overlap.load(std::memory_order_relaxed);
     o.needle_group = g_opt_needle_group.load(std::memory_order_relaxed);
     o.dense = g_opt_dense.load(std::memory_order_relaxed);
-    o.k2_oop = g_opt_k2_oop.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -416,11 +414,6 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     long long ppg = std::max<long long>(1, o.pairs_per_group);
     if (ppg > npairs) ppg = npairs;
     if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
-    float2* k2_dst = nullptr;   // K2 in place, or into a second work matrix that K3 then reads
-    if (o.k2_oop) {
-        if ((rc = c->work2.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
-        k2_dst = (float2*)c->work2.p;
-    }
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
@@ -458,10 +451,10 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         const int np = (int)std::min(ppg, pair_hi - first);
         job.first_pair = (int)first;
         { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, k2_dst, half, hscale)); }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
         if (!waited && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
         waited = true;
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, k2_dst ? (const float2*)k2_dst : (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
     }
     return AM_OK;
 }
@@ -1610,7 +1603,6 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
-    if (!strcmp(key, "k2_out_of_place")) { g_opt_k2_oop = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
         if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
         g_opt_needle_group = value; return AM_OK;
@@ -1630,7 +1622,6 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
-    if (!strcmp(key, "k2_out_of_place")) { *value = g_opt_k2_oop; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }

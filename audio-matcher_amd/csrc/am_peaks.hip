@@ -303,16 +303,30 @@ struct ChunkView {
     float seg_min, min_prom;
 };
 
-// scan from `from` in direction `step` until (exclusive) w_end; returns true when the side is
-// settled (a strictly higher score was met, or w_end is the chunk edge c_end)
-__device__ __forceinline__ bool side_scan(const float* win, long long win_lo, long long from, long long step,
-                                          long long w_end, long long c_end, float h, float& mn) {
-    for (long long j = from; j != w_end; j += step) {
-        const float v = win[j - win_lo];
+// Scan window offsets from `from` in direction STEP until (exclusive) `end`; returns true when a
+// strictly higher score was met (mn = minimum of the scores before it).  Eight scores are
+// fetched from LDS per trip and then looked at in order: a one-score-per-trip loop would pay the
+// LDS latency once per score.
+template <int STEP>
+__device__ __forceinline__ bool side_scan(const float* win, int from, int end, float h, float& mn) {
+    int j = from;
+    while ((end - j) * STEP >= 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = win[j + q * STEP];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (v[q] > h) return true;
+            mn = fminf(mn, v[q]);
+        }
+        j += 8 * STEP;
+    }
+    for (; j != end; j += STEP) {
+        const float v = win[j];
         if (v > h) return true;
         mn = fminf(mn, v);
     }
-    return w_end == c_end;
+    return false;
 }
 
 template <class Emit>
@@ -335,10 +349,11 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
         while (k < b - 1 && (k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) == x) ++k;
         if (!((k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) < x)) continue;
         // flat-topped maximum [i, k) of height x: settle it inside the window if possible
+        // (a side is settled by a strictly higher score, or by the chunk edge inside the window)
         float lmn = x, rmn = x;
-        const bool dl = side_scan(win, w_lo, i - 1, -1, w_lo - 1, a - 1, x, lmn);
+        const bool dl = side_scan<-1>(win, (int)(i - 1 - w_lo), -1, x, lmn) || w_lo == a;
         if (dl && !((x - lmn) >= cv.min_prom)) continue;
-        const bool dr = k <= w_hi && side_scan(win, w_lo, k, 1, w_hi, b, x, rmn);
+        const bool dr = k <= w_hi && (side_scan<1>(win, (int)(k - w_lo), (int)(w_hi - w_lo), x, rmn) || w_hi == b);
         if (dr && !((x - rmn) >= cv.min_prom)) continue;
         if (dl && dr) {
             emit((long long)i, k, x, x - fmaxf(lmn, rmn));
