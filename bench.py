@@ -206,13 +206,13 @@ class Rank:
             self.dist.destroy_process_group()
 
 
-def strong_batch(am, R, device, algo, needle, params, total, steps, s, h):
+def strong_batch(am, R, device, algo, needle, params, total, steps, s, h, ranks_per_device=1):
     """`steps` passes over a batch of `total` haystacks, haystack k on rank k mod world.
     Resident waves: what fits the per-GPU budget is generated on device (untimed), matched
     with one am_match_batch_device call (timed), verified, and its buffers reused for the
     next wave.  Returns (seconds of the slowest rank summed over waves and steps, wave size)."""
     mine = shard(total, R.rank, R.world)
-    per_wave = max(1, int(RESIDENT_BUDGET_BYTES // (4 * h)))
+    per_wave = max(1, int(RESIDENT_BUDGET_BYTES // ranks_per_device // (4 * h)))
     n_buf = min(per_wave, max(1, len(mine)))
     bufs = [am.DeviceBuffer(device, 4 * h) for _ in range(n_buf)]
     local = 0.0
@@ -281,6 +281,7 @@ def main():
     params = cfg.params(SR, am.Scale.LIB)
     strong = args.total_haystacks > 0
     B = args.haystacks_per_step
+    rpd = -(-R.world // ndev)          # ranks sharing one device (1 on a full node; a rehearsal on fewer GPUs shares)
 
     def sync():
         am._check(am.lib().am_device_synchronize(device))
@@ -324,9 +325,9 @@ def main():
         launches_per_step = B
     else:
         am.set_option("profile_mask", 1 << KN.index("k2_rows"))
-        strong_batch(am, R, device, algo, needle, params, args.total_haystacks, max(1, min(args.warmup, 1)), s, h)
+        strong_batch(am, R, device, algo, needle, params, args.total_haystacks, max(1, min(args.warmup, 1)), s, h, rpd)
         with am.Profile(device) as prof:
-            local_dt, wave = strong_batch(am, R, device, algo, needle, params, args.total_haystacks, args.steps, s, h)
+            local_dt, wave = strong_batch(am, R, device, algo, needle, params, args.total_haystacks, args.steps, s, h, rpd)
             dom_timed = prof.query("k2_rows")
         units_per_step = float(h) * args.total_haystacks
         launches_per_step = len(shard(args.total_haystacks, R.rank, R.world))
@@ -354,7 +355,7 @@ def main():
     # the north-star batch as an extra leg: 1000 haystacks, strong scaling, one pass
     batch_1000 = None
     if not strong and not args.no_batch_1000:
-        b_local, b_wave = strong_batch(am, R, device, algo, needle, params, 1000, 1, s, h)
+        b_local, b_wave = strong_batch(am, R, device, algo, needle, params, 1000, 1, s, h, rpd)
         b_dt = R.max_all(b_local)
         b_parts = R.gather(round(b_local, 6))
         batch_1000 = {"value": 1000.0 * h / b_dt, "unit": "samples/s", "scaling": "strong", "n_gpus": R.world,
@@ -409,7 +410,7 @@ def main():
                                 f"resident in HBM (BASELINE configs[1] shape); 6 planted hits per haystack, every result verified"),
                    "needle_samples": s, "haystack_samples": h, "haystacks_per_rank_per_step": hay_per_rank_step,
                    "fft_log2": log_n, "hop": hop, "ramp_steps": args.ramp_steps, "timed_region_ms": timed_ms,
-                   "devices_visible_per_rank": ndev, "per_rank_seconds": per_rank,
+                   "devices_visible_per_rank": ndev, "ranks_per_device": rpd, "per_rank_seconds": per_rank,
                    "sharding": f"{R.world} rank(s), independent haystacks, no collective"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
