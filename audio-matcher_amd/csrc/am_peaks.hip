@@ -282,17 +282,23 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 // maxima with flat tops whose height can qualify, then their prominence.
 //
 // The piece and a halo of kHalo scores on either side are staged in LDS first (as
-// score_for_min sees them: raw where written, the run's exact minimum elsewhere).  Every
-// thread that finds a maximum then looks outwards through that window by itself:
-//   * a strictly higher score before the running minimum has dropped by min_prom settles
-//     that side against the candidate (prominence = h - max(lmin, rmin) < min_prom): rejected
-//     without a walk -- this is what almost every maximum of an oscillating score array is;
-//   * both sides settled (higher score or chunk edge inside the window): accepted with its
-//     exact prominence, again without a walk;
-//   * otherwise the candidate is queued for the wave-cooperative walk (prominence()).
-// The arithmetic is the walk's own (same minima over the same scores, same comparisons), so
-// the outcome is bit-identical to walking every candidate.
+// score_for_min sees them: raw where written, the run's exact minimum elsewhere).  A
+// candidate is then settled as cheaply as possible, in three stages of growing cost:
+//   1. its own thread looks kNear scores to either side.  A score array that is not white
+//      has a local maximum every few scores (noise on top of whatever moves slowly), and for
+//      almost all of them a strictly higher score lies a few positions away, before the
+//      running minimum has dropped by min_prom: prominence = h - max(lmin, rmin) < min_prom,
+//      rejected after a handful of LDS reads;
+//   2. what survives (the top of each ripple crest, say) is looked at by a whole wavefront,
+//      64 scores of the LDS window per step: rejected as above, or -- both sides settled
+//      inside the window by a higher score or the chunk edge -- accepted with its exact
+//      prominence;
+//   3. only a candidate that is the highest score of its whole window on some side goes on the
+//      wave-cooperative walk through global memory (prominence()).
+// All three use the walk's own arithmetic (the same minima over the same scores, the same
+// comparisons), so the outcome is bit-identical to walking every candidate.
 constexpr int kHalo = 256;
+constexpr int kNear = 32;
 constexpr int kWin = kTile + 2 * kHalo;
 
 struct ChunkView {
@@ -329,6 +335,22 @@ __device__ __forceinline__ bool side_scan(const float* win, int from, int end, f
     return false;
 }
 
+// The same by a whole wavefront, 64 window offsets per step (all lanes take part).
+template <int STEP>
+__device__ __forceinline__ bool side_scan_wave(const float* win, int from, int end, float h, float& mn, int lane) {
+    for (int j = from; (end - j) * STEP > 0; j += 64 * STEP) {
+        const int idx = j + lane * STEP;
+        const bool valid = (end - idx) * STEP > 0;
+        const float v = valid ? win[idx] : 0.0f;
+        const unsigned long long higher = __ballot(valid && v > h);
+        const int nval = __popcll(__ballot(valid));
+        const int ntake = higher ? (__ffsll((long long)higher) - 1) : nval;
+        mn = fminf(mn, wave_min(lane < ntake ? v : FLT_MAX));
+        if (higher) return true;
+    }
+    return false;
+}
+
 template <class Emit>
 __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, float* win, Cand* queue, int* queue_n,
                            int* overflow, int tid, Emit emit) {
@@ -337,27 +359,33 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
     // window [w_lo, w_hi) = piece + halo, clipped to the chunk
     const long long w_lo = lo - kHalo > a ? lo - kHalo : a;
     const long long w_hi = hi + kHalo < b ? hi + kHalo : b;
+    const int wn = (int)(w_hi - w_lo);
     for (long long i = w_lo + tid; i < w_hi; i += kPeakThreads) win[i - w_lo] = score_for_min(cv.g, cv.sp, i);
     __syncthreads();
     for (long long i = lo + tid; i < hi; i += kPeakThreads) {
         if (i <= a || i >= b - 1) continue;
-        const float x = win[i - w_lo];
+        const int wi = (int)(i - w_lo);
+        const float x = win[wi];
         // (an unwritten score shows its run's minimum here, which is below theta and therefore
         // fails this test whenever the chunk's certificate holds)
-        if (!((x - cv.seg_min) >= cv.min_prom) || !(win[i - 1 - w_lo] < x)) continue;
+        if (!((x - cv.seg_min) >= cv.min_prom) || !(win[wi - 1] < x)) continue;
         long long k = i + 1;
         while (k < b - 1 && (k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) == x) ++k;
         if (!((k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) < x)) continue;
-        // flat-topped maximum [i, k) of height x: settle it inside the window if possible
-        // (a side is settled by a strictly higher score, or by the chunk edge inside the window)
-        float lmn = x, rmn = x;
-        const bool dl = side_scan<-1>(win, (int)(i - 1 - w_lo), -1, x, lmn) || w_lo == a;
-        if (dl && !((x - lmn) >= cv.min_prom)) continue;
-        const bool dr = k <= w_hi && (side_scan<1>(win, (int)(k - w_lo), (int)(w_hi - w_lo), x, rmn) || w_hi == b);
-        if (dr && !((x - rmn) >= cv.min_prom)) continue;
-        if (dl && dr) {
-            emit((long long)i, k, x, x - fmaxf(lmn, rmn));
-            continue;
+        // stage 1: flat-topped maximum [i, k) of height x against its kNear neighbours on either side
+        // (a side is settled by a strictly higher score, or by the chunk edge)
+        if (k <= w_hi) {
+            const int wk = (int)(k - w_lo);
+            const int l_end = wi - 1 - kNear > -1 ? wi - 1 - kNear : -1, r_end = wk + kNear < wn ? wk + kNear : wn;
+            float lmn = x, rmn = x;
+            const bool dl = side_scan<-1>(win, wi - 1, l_end, x, lmn) || (l_end == -1 && w_lo == a);
+            if (dl && !((x - lmn) >= cv.min_prom)) continue;
+            const bool dr = side_scan<1>(win, wk, r_end, x, rmn) || (r_end == wn && w_hi == b);
+            if (dr && !((x - rmn) >= cv.min_prom)) continue;
+            if (dl && dr) {
+                emit((long long)i, k, x, x - fmaxf(lmn, rmn));
+                continue;
+            }
         }
         const int slot = atomicAdd(queue_n, 1);
         if (slot < kQueueCap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
@@ -365,9 +393,21 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
     }
     __syncthreads();
     const int qn = *queue_n < kQueueCap ? *queue_n : kQueueCap;
-    // -- prominence by walking, one wavefront per remaining candidate --
     for (int q = wv; q < qn; q += kWaves) {
         const Cand cd = queue[q];
+        // stage 2: the whole window, one wavefront per candidate
+        if (cd.pe <= w_hi) {
+            float lmn = cd.h, rmn = cd.h;
+            const bool dl = side_scan_wave<-1>(win, (int)(cd.ps - 1 - w_lo), -1, cd.h, lmn, lane) || w_lo == a;
+            if (dl && !((cd.h - lmn) >= cv.min_prom)) continue;
+            const bool dr = side_scan_wave<1>(win, (int)(cd.pe - w_lo), wn, cd.h, rmn, lane) || w_hi == b;
+            if (dr && !((cd.h - rmn) >= cv.min_prom)) continue;
+            if (dl && dr) {
+                if (lane == 0) emit(cd.ps, cd.pe, cd.h, cd.h - fmaxf(lmn, rmn));
+                continue;
+            }
+        }
+        // stage 3: the walk through global memory
         float prom = 0.0f;
         const bool keep = prominence(cv.g, cv.stats, cv.sp, a, b, cd.ps, cd.pe, cd.h, cv.min_prom, lane, prom);
         if (keep && lane == 0) emit(cd.ps, cd.pe, cd.h, prom);
