@@ -352,7 +352,7 @@ __device__ __forceinline__ bool side_scan_wave(const float* win, int from, int e
 }
 
 template <class Emit>
-__device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, float* win, Cand* queue, int* queue_n,
+__device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, float* win, Cand* queue, int qcap, int* queue_n,
                            int* overflow, int tid, Emit emit) {
     const int lane = tid & 63, wv = tid >> 6;
     const long long a = cv.a, b = cv.b;
@@ -388,11 +388,11 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
             }
         }
         const int slot = atomicAdd(queue_n, 1);
-        if (slot < kQueueCap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
+        if (slot < qcap) { queue[slot].ps = i; queue[slot].pe = k; queue[slot].h = x; }
         else *overflow = 1;
     }
     __syncthreads();
-    const int qn = *queue_n < kQueueCap ? *queue_n : kQueueCap;
+    const int qn = *queue_n < qcap ? *queue_n : qcap;
     for (int q = wv; q < qn; q += kWaves) {
         const Cand cd = queue[q];
         // stage 2: the whole window, one wavefront per candidate
@@ -480,7 +480,9 @@ __device__ void finish_chunk(am_peak* res, int rn, int* order, int overflow, lon
 // has thousands of candidate maxima per chunk; one workgroup per chunk would leave 196 of
 // the 256 CUs idle for tens of milliseconds.)
 constexpr int kWideTiles = 48;
-constexpr int kWideParts = 16;
+constexpr int kWideParts = 64;
+// a piece of at most kTile scores has at most kTile / 2 flat-topped maxima: the queue cannot overflow
+constexpr int kWideQueue = kTile / 2;
 
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
@@ -654,7 +656,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
             if (all_tiles && !((stats[t].y - seg_min) >= min_prom)) continue;
         }
         if (hi <= lo) continue;
-        scan_piece(cv, lo, hi, win, queue, &queue_n, &overflow, tid, emit);
+        scan_piece(cv, lo, hi, win, queue, kQueueCap, &queue_n, &overflow, tid, emit);
     }
     const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
     finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid);
@@ -666,7 +668,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
            const Segment* __restrict__ segs, float min_prom, SparseScores sp, WideState wide) {
-    __shared__ Cand queue[kQueueCap];
+    __shared__ Cand queue[kWideQueue];
     __shared__ int queue_n;
     __shared__ int overflow;
     __shared__ float win[kWin];
@@ -691,12 +693,12 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
             list[slot] = pk;
         }
     };
-    if (part == 0 && head_hi > a) scan_piece(cv, a, head_hi, win, queue, &queue_n, &overflow, tid, emit);
-    if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, queue, &queue_n, &overflow, tid, emit);
+    if (part == 0 && head_hi > a) scan_piece(cv, a, head_hi, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+    if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
     if (has_full)
         for (long long t = tf + part; t < tl; t += kWideParts) {
             if (!((stats[t].y - seg_min) >= min_prom)) continue;
-            scan_piece(cv, t * kTile, (t + 1) * kTile, win, queue, &queue_n, &overflow, tid, emit);
+            scan_piece(cv, t * kTile, (t + 1) * kTile, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
         }
     if (tid == 0 && overflow) atomicAdd(&wide.count[seg], (unsigned)AM_MAX_PEAKS_PER_CHUNK + 1u);   // poisons the count: reported as overflow
 }
