@@ -245,12 +245,23 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     R = Rank(args)
+    # stdout carries exactly one JSON line (rank 0's); everything else a library may print there
+    # (gloo's connection messages, for one) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
 
     if args.dry_shard:
         total = args.total_haystacks or 1000
         mine = shard(total, R.rank, R.world)
-        print(json.dumps({"rank": R.rank, "world": R.world, "total_haystacks": total, "count": len(mine),
-                          "first": mine[:3], "last": mine[-1] if mine else None}), flush=True)
+        emit(json.dumps({"rank": R.rank, "world": R.world, "total_haystacks": total, "count": len(mine),
+                         "first": mine[:3], "last": mine[-1] if mine else None}))
         import audiomatch_amd as am
         if am.device_count() < 1:
             raise SystemExit(f"rank {R.rank}: bench.py needs a HIP device; there is no CPU fallback")
@@ -440,7 +451,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(chunks, threads, "reference")
         out["cpu_baseline_pow2"] = cpu_baseline(chunks, threads, "pow2_cached")             # row C1
         out["cpu_baseline_config1"] = cpu_baseline(1, 1, "reference")                       # configs[0]: 10 s vs 60 s, one chunk
-    print(json.dumps(out))
+    emit(json.dumps(out))
     R.close()
 
 
