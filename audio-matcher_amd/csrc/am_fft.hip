@@ -693,26 +693,39 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
-// Score-scan exchange of K3: the workgroup's 256 x 32 scores of one block go
-// through LDS once so that thread t ends up with the whole 32-score run of row t
-// (16-byte chunk c of row r sits at chunk position c ^ (r & 7): both the 8-byte
-// writes of the column owners and the 16-byte reads of the row owners are
-// conflict-free).  (min, max) of a run then cost 16 + 16 three-input operations.
-__device__ __forceinline__ void scan_put(float2* lds2, unsigned wbase, const float (&c0)[16], const float (&c1)[16]) {
+// Score-scan exchange of K3: the workgroup's 256 x 32 scores of one block go through LDS
+// once so that every thread ends up with the whole 32-score run of one row; (min, max) of a
+// run then cost 16 + 16 three-input operations.
+// The column owner (hi, cp) holds rows a*16 + hi, a = 0..15, and a wavefront holds four
+// values of hi, so the 32 scores of a row are written by 16 lanes of ONE wavefront.  The row is
+// therefore read back by a lane of that same wavefront -- lane l of wave w takes row
+// r = (l >> 2) * 16 + 4 w + (l & 3) -- and the exchange needs no workgroup barrier, only the
+// wavefront's own ordering (wave_sync_lds).  16-byte chunk c of row r sits at chunk position
+// c ^ s(r), s(r) = ((r >> 4) & 3) << 1 | ((r & 3) >> 1): with it both the 8-byte writes of the
+// column owners and the 16-byte reads of the row owners are conflict-free (every 16-lane group
+// of a ds_read_b128 meets all 16 chunk columns once).
+__device__ __forceinline__ unsigned scan_swizzle(unsigned row) { return (((row >> 4) & 3u) << 1) | ((row & 3u) >> 1); }
+__device__ __forceinline__ int scan_row_of(int t) { return ((t & 63) >> 2) * 16 + (t >> 6) * 4 + (t & 3); }
+__device__ __forceinline__ void scan_put(float2* lds2, int hi, int cp, const float (&c0)[16], const float (&c1)[16]) {
+    const unsigned half = (unsigned)cp & 1u, chunk = (unsigned)cp >> 1, hb = ((unsigned)hi & 3u) >> 1;
 #pragma unroll
-    for (int a = 0; a < 16; ++a) lds2[a * 256 + wbase] = make_float2(c0[a], c1[a]);
+    for (int a = 0; a < 16; ++a) {
+        const unsigned pos = chunk ^ ((((unsigned)a & 3u) << 1) | hb);
+        lds2[a * 256 + hi * 16 + (int)((pos << 1) | half)] = make_float2(c0[a], c1[a]);
+    }
 }
-// whole = every score of the run is valid; otherwise scores at run offsets >= nvalid are ignored
-__device__ __forceinline__ void scan_row_minmax(const float4* lds4, int t, bool whole, int nvalid, float& mn, float& mx) {
-    const unsigned k = (unsigned)t & 7u;
+// row = the run's row; whole = every score of the run is valid, otherwise scores at run offsets
+// >= nvalid are ignored
+__device__ __forceinline__ void scan_row_minmax(const float4* lds4, int row, bool whole, int nvalid, float& mn, float& mx) {
+    const unsigned k = scan_swizzle((unsigned)row);
     float4 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = lds4[t * 8 + (int)((unsigned)i ^ k)];
+    for (int i = 0; i < 8; ++i) v[i] = lds4[row * 8 + (int)((unsigned)i ^ k)];
     if (!whole) {
         mn = FLT_MAX; mx = -FLT_MAX;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int c0 = (int)(((unsigned)i ^ k) << 2);   // first run offset held by this chunk
+            const int c0 = i << 2;   // first run offset held by chunk i
             const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -836,23 +849,23 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     bool wantA = true, wantB = true;
     if (scan.stats32 != nullptr) {
         // ---- fused score scan: (min,max) per 32 consecutive scores ------------
-        // thread t owns the run of row n1 = t (scores t*out_stride + n2_0 .. +31 of both blocks)
-        const long long rowrun = (long long)t * out_stride + n2_0;
+        // this thread owns the run of row n1 = row (scores row*out_stride + n2_0 .. +31 of both blocks)
+        const int row = scan_row_of(t);
+        const long long rowrun = (long long)row * out_stride + n2_0;
         // Every run is wholly valid or wholly invalid, except in the block that holds
         // the end of the score array.
         const long long leftA = limA - rowrun, leftB = limB - rowrun;
         const bool wholeA = leftA >= 32 || leftA <= 0, wholeB = leftB >= 32 || leftB <= 0;
-        const unsigned wbase = (unsigned)hi * 16u + ((((unsigned)cp >> 1) ^ ((unsigned)hi & 7u)) << 1) + ((unsigned)cp & 1u);
         const float4* lds4 = reinterpret_cast<const float4*>(lds2);
         float rmnA, rmxA, rmnB, rmxB;
-        __syncthreads();   // the column exchange above is finished with the tile
-        scan_put(lds2, wbase, sa0, sa1);
-        __syncthreads();
-        scan_row_minmax(lds4, t, wholeA, (int)(leftA < 32 ? leftA : 32), rmnA, rmxA);
-        __syncthreads();
-        scan_put(lds2, wbase, sb0, sb1);
-        __syncthreads();
-        scan_row_minmax(lds4, t, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
+        __syncthreads();   // the column exchange above is finished with the tile (it crosses wavefronts)
+        scan_put(lds2, hi, cp, sa0, sa1);
+        wave_sync_lds();   // a row is written and read by lanes of one wavefront
+        scan_row_minmax(lds4, row, wholeA, (int)(leftA < 32 ? leftA : 32), rmnA, rmxA);
+        wave_sync_lds();
+        scan_put(lds2, hi, cp, sb0, sb1);
+        wave_sync_lds();
+        scan_row_minmax(lds4, row, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
         // raw scores leave the chip only for tiles that can matter to the peak
         // pick: some score >= theta, or a run that straddles a chunk edge
         bool edgeA, edgeB;
@@ -945,40 +958,43 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 // K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
 // the inverse 8192-point transforms e / o of the even / odd row frequencies;
 // y[m] = e + conj(W_16384^m) o and y[m + 8192] = e - conj(W_16384^m) o are the two
-// column tiles m and m + 8192.  Each workgroup produces ONE of the two tiles (so it
-// keeps the register footprint and occupancy of the 2^21 kernel) and therefore
-// reads both row halves; the two workgroups of a tile pair are adjacent on one XCD,
-// so the second read of a line is served by that L2.
-__global__ void __launch_bounds__(256, 3)
+// column tiles m and m + 8192.  One workgroup reads e and o once (nontemporal: nobody
+// reads them again) and produces BOTH tiles one after the other; the second tile's
+// inputs wait in registers meanwhile (two workgroups per CU, each with two tiles of loads
+// in flight).  Producing one tile per workgroup and reading both row halves twice (the
+// second time from L2) kept four workgroups per CU but cost 0.205 ms against 0.144 ms
+// for the same points on the 2^21 plan.
+__global__ void __launch_bounds__(256, 2)
 k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     __shared__ K3Shared sh;
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned h = seq & 1u, rest = seq >> 1;
-    const unsigned slot = rest >> 5, half = (rest >> 4) & 1u, tl = rest & 15u;
+    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
     const int m_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
     const long long blkA = 2ll * pair, blkB = blkA + 1;
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned m = (unsigned)m_0 + 2u * (unsigned)cp;
-    const float sgn = h ? -1.0f : 1.0f;
     float2 wd0 = tw_big(pl, (m * 256u) & maskN);
     float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
-    wd0 = make_float2(sgn * wd0.x, -sgn * wd0.y);   // +-conj(W_16384^m)
-    wd1 = make_float2(sgn * wd1.x, -sgn * wd1.y);
-    float2 x0[16], x1[16];
+    wd0.y = -wd0.y;   // conj(W_16384^m)
+    wd1.y = -wd1.y;
+    float2 x0[16], x1[16], y0[16], y1[16];
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + m_0) + cp;
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
         const size_t k1 = (size_t)(hi + 16 * bp);
-        const float4 ve = in4[(2 * k1) * (kN2 / 2)], vo = in4[(2 * k1 + 1) * (kN2 / 2)];
-        x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
-        x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
+        const float4 ve = load_f4<1>(in4 + (2 * k1) * (kN2 / 2)), vo = load_f4<1>(in4 + (2 * k1 + 1) * (kN2 / 2));
+        const float2 p0 = cmul(make_float2(vo.x, vo.y), wd0), p1 = cmul(make_float2(vo.z, vo.w), wd1);
+        x0[bp] = cadd(make_float2(ve.x, ve.y), p0); y0[bp] = csub(make_float2(ve.x, ve.y), p0);
+        x1[bp] = cadd(make_float2(ve.z, ve.w), p1); y1[bp] = csub(make_float2(ve.z, ve.w), p1);
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
+    __syncthreads();   // the first tile is finished with LDS and the vote words
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + kN2, 2 * kN2, t, blkA, blkB, out_scale, y0, y1);
 }
 
 // ===========================================================================
@@ -1302,7 +1318,7 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl) && pl.wide) {
-        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * 2u * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                            pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
