@@ -267,28 +267,25 @@ __device__ __forceinline__ float2 load2_padded(const void* __restrict__ src, lon
     return v;
 }
 
-// K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
-// FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
-// holds frequency k1 in natural order.
-// One column tile of K1: loads rows n1 = a*16 + b of 2 adjacent columns (sample
-// index n1 * in_stride + col in both packed blocks), 256-point column FFT (two
-// passes with one LDS exchange), pipeline twiddle W_N^(col*k1).  On return
-// x0/x1[brev(b')] hold row k1 = hi + 16*b' of columns col, col+1.
+// the table lookups of one tile: W_256^b for the pass boundary and W_N^(n2*a'), W_N^(16*n2)
+// for the pipeline twiddle (k1 = a' + 16*b', a' = hi), requested before the samples so that
+// their latency overlaps the streaming loads
+struct K1Twiddles { float2 w256, base0, base1, step0, step1; };
+__device__ __forceinline__ K1Twiddles k1_twiddles(const PlanDev& pl, long long col, int hi) {
+    const unsigned maskN = (unsigned)((1ll << pl.logN) - 1);
+    K1Twiddles w;
+    w.w256 = pl.tw1[hi];
+    w.base0 = tw_big(pl, ((unsigned)col * (unsigned)hi) & maskN);
+    w.base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)hi) & maskN);
+    w.step0 = tw_big(pl, ((unsigned)col * 16u) & maskN);
+    w.step1 = tw_big(pl, (((unsigned)col + 1u) * 16u) & maskN);
+    return w;
+}
+// pass 1 ownership: rows n1 = a*16 + hi of columns col, col+1 (sample index n1 * in_stride + col
+// in both packed blocks): real part = block A, imaginary part = block B
 template <int KIND>
-__device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float2* lds2, long long col, int in_stride,
-                                        int hi, int cp, long long baseA, long long baseB, bool validB, bool fast,
-                                        float2 (&x0)[16], float2 (&x1)[16]) {
-    const long long N = 1ll << pl.logN;
-    // every table lookup this tile needs, issued before the samples so that their
-    // latency overlaps the streaming loads: W_256^b for the pass boundary and
-    // W_N^(n2*a'), W_N^(16*n2) for the pipeline twiddle (k1 = a' + 16*b', a' = hi)
-    const unsigned maskN = (unsigned)(N - 1);
-    const float2 w256 = pl.tw1[hi];
-    const float2 base0 = tw_big(pl, ((unsigned)col * (unsigned)hi) & maskN);
-    const float2 base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)hi) & maskN);
-    const float2 step0 = tw_big(pl, ((unsigned)col * 16u) & maskN);
-    const float2 step1 = tw_big(pl, (((unsigned)col + 1u) * 16u) & maskN);
-    // pass 1 ownership: b = hi (n1 = a*16 + b), columns col, col+1
+__device__ __forceinline__ void k1_load(const Job& job, long long col, int in_stride, int hi, long long baseA, long long baseB,
+                                        bool validB, bool fast, float2 (&x0)[16], float2 (&x1)[16]) {
     if (fast) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
@@ -307,10 +304,14 @@ __device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float
             x1[a] = make_float2(va.y, vb.y);
         }
     }
+}
+// 256-point column FFT (two passes with one LDS exchange) + pipeline twiddle W_N^(col*k1).
+// On return x0/x1[brev(b')] hold row k1 = hi + 16*b' of columns col, col+1.
+__device__ __forceinline__ void k1_transform(const K1Twiddles& w, float2* lds2, int hi, int cp, float2 (&x0)[16], float2 (&x1)[16]) {
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, w256);   // W_256^(b*a')
-    twiddle_brev<16, false>(x1, w256);
+    twiddle_brev<16, false>(x0, w.w256);   // W_256^(b*a')
+    twiddle_brev<16, false>(x1, w.w256);
     // Exchange between the two passes, one column of the pair at a time so that a
     // workgroup needs 34 KB of LDS (row stride 17 keeps the 8-byte reads of rows
     // 16 apart on disjoint banks): pass 2 owns a' = hi, b = 0..15.
@@ -328,8 +329,19 @@ __device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float
     dif<16, false>(x0);
     dif<16, false>(x1);
     // k1 = a' + 16*b';  W_N^(n2*k1) = W_N^(n2*a') * (W_N^(16*n2))^b'
-    twiddle_chain<16, false, true>(x0, base0, step0);
-    twiddle_chain<16, false, true>(x1, base1, step1);
+    twiddle_chain<16, false, true>(x0, w.base0, w.step0);
+    twiddle_chain<16, false, true>(x1, w.base1, w.step1);
+}
+// K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
+// FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
+// holds frequency k1 in natural order.
+template <int KIND>
+__device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float2* lds2, long long col, int in_stride,
+                                        int hi, int cp, long long baseA, long long baseB, bool validB, bool fast,
+                                        float2 (&x0)[16], float2 (&x1)[16]) {
+    const K1Twiddles w = k1_twiddles(pl, col, hi);
+    k1_load<KIND>(job, col, in_stride, hi, baseA, baseB, validB, fast, x0, x1);
+    k1_transform(w, lds2, hi, cp, x0, x1);
 }
 
 template <int KIND, bool HALF>
@@ -394,9 +406,14 @@ k1_cols_fwd_w16(Job job, float2* __restrict__ work, PlanDev pl) {
     const float2 wd1 = tw_big(pl, (((unsigned)m + 1u) * 256u) & maskN);
     float2 a0[16], a1[16], x0[16], x1[16];
     float2* lds2 = reinterpret_cast<float2*>(lds4);
-    k1_tile<KIND>(job, pl, lds2, m, 2 * kN2, hi, cp, baseA, baseB, validB, fast, a0, a1);
+    // both tiles' samples are requested before the first transform starts: the second tile's
+    // loads are in flight while the first is computed
+    const K1Twiddles wa = k1_twiddles(pl, m, hi), wx = k1_twiddles(pl, m + kN2, hi);
+    k1_load<KIND>(job, m, 2 * kN2, hi, baseA, baseB, validB, fast, a0, a1);
+    k1_load<KIND>(job, m + kN2, 2 * kN2, hi, baseA, baseB, validB, fast, x0, x1);
+    k1_transform(wa, lds2, hi, cp, a0, a1);
     __syncthreads();   // the LDS tile is reused
-    k1_tile<KIND>(job, pl, lds2, m + kN2, 2 * kN2, hi, cp, baseA, baseB, validB, fast, x0, x1);
+    k1_transform(wx, lds2, hi, cp, x0, x1);
     float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + m_0) + cp;
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
@@ -958,43 +975,40 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 // K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
 // the inverse 8192-point transforms e / o of the even / odd row frequencies;
 // y[m] = e + conj(W_16384^m) o and y[m + 8192] = e - conj(W_16384^m) o are the two
-// column tiles m and m + 8192.  One workgroup reads e and o once (nontemporal: nobody
-// reads them again) and produces BOTH tiles one after the other; the second tile's
-// inputs wait in registers meanwhile (two workgroups per CU, each with two tiles of loads
-// in flight).  Producing one tile per workgroup and reading both row halves twice (the
-// second time from L2) kept four workgroups per CU but cost 0.205 ms against 0.144 ms
-// for the same points on the 2^21 plan.
-__global__ void __launch_bounds__(256, 2)
+// column tiles m and m + 8192.  Each workgroup produces ONE of the two tiles (so it
+// keeps the register footprint and occupancy of the 2^21 kernel) and therefore
+// reads both row halves; the two workgroups of a tile pair are adjacent on one XCD,
+// so the second read of a line is served by that L2.
+__global__ void __launch_bounds__(256, 3)
 k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     __shared__ K3Shared sh;
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
+    const unsigned h = seq & 1u, rest = seq >> 1;
+    const unsigned slot = rest >> 5, half = (rest >> 4) & 1u, tl = rest & 15u;
     const int m_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
     const long long blkA = 2ll * pair, blkB = blkA + 1;
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned m = (unsigned)m_0 + 2u * (unsigned)cp;
+    const float sgn = h ? -1.0f : 1.0f;
     float2 wd0 = tw_big(pl, (m * 256u) & maskN);
     float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
-    wd0.y = -wd0.y;   // conj(W_16384^m)
-    wd1.y = -wd1.y;
-    float2 x0[16], x1[16], y0[16], y1[16];
+    wd0 = make_float2(sgn * wd0.x, -sgn * wd0.y);   // +-conj(W_16384^m)
+    wd1 = make_float2(sgn * wd1.x, -sgn * wd1.y);
+    float2 x0[16], x1[16];
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + m_0) + cp;
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
         const size_t k1 = (size_t)(hi + 16 * bp);
-        const float4 ve = load_f4<1>(in4 + (2 * k1) * (kN2 / 2)), vo = load_f4<1>(in4 + (2 * k1 + 1) * (kN2 / 2));
-        const float2 p0 = cmul(make_float2(vo.x, vo.y), wd0), p1 = cmul(make_float2(vo.z, vo.w), wd1);
-        x0[bp] = cadd(make_float2(ve.x, ve.y), p0); y0[bp] = csub(make_float2(ve.x, ve.y), p0);
-        x1[bp] = cadd(make_float2(ve.z, ve.w), p1); y1[bp] = csub(make_float2(ve.z, ve.w), p1);
+        const float4 ve = in4[(2 * k1) * (kN2 / 2)], vo = in4[(2 * k1 + 1) * (kN2 / 2)];
+        x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
+        x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
-    __syncthreads();   // the first tile is finished with LDS and the vote words
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + kN2, 2 * kN2, t, blkA, blkB, out_scale, y0, y1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -1318,7 +1332,7 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_r16(pl) && pl.wide) {
-        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * 2u * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                            pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
