@@ -28,7 +28,7 @@ namespace am {
 
 constexpr int kPeakThreads = 256;
 constexpr int kWaves = kPeakThreads / 64;
-constexpr int kQueueCap = kTile;  // local maxima of one tile (<= kTile/2, head/tail pieces < kTile)
+constexpr int kQueueCap = kTile / 2;  // a piece of at most kTile scores has at most kTile / 2 flat-topped maxima
 constexpr int kGroup = 8;         // tiles per lane in the coarse step of a prominence walk
 constexpr int kCandCap = 1024;    // candidate tiles listed per chunk before falling back to all tiles
 
@@ -655,8 +655,10 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
             lo = t * kTile; hi = lo + kTile;
             if (all_tiles && !((stats[t].y - seg_min) >= min_prom)) continue;
         }
-        if (hi <= lo) continue;
-        scan_piece(cv, lo, hi, win, queue, kQueueCap, &queue_n, &overflow, tid, emit);
+        // (a chunk without a full tile inside has a head piece of up to 2 * kTile - 2 scores:
+        // the LDS window holds kTile + halo, so long pieces go in slices)
+        for (long long q0 = lo; q0 < hi; q0 += kTile)
+            scan_piece(cv, q0, q0 + kTile < hi ? q0 + kTile : hi, win, queue, kQueueCap, &queue_n, &overflow, tid, emit);
     }
     const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
     finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid);
@@ -693,7 +695,9 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
             list[slot] = pk;
         }
     };
-    if (part == 0 && head_hi > a) scan_piece(cv, a, head_hi, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+    if (part == 0)
+        for (long long q0 = a; q0 < head_hi; q0 += kTile)
+            scan_piece(cv, q0, q0 + kTile < head_hi ? q0 + kTile : head_hi, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
     if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
     if (has_full)
         for (long long t = tf + part; t < tl; t += kWideParts) {

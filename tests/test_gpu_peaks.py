@@ -73,3 +73,17 @@ def test_far_walks_use_tile_summaries(gpu, oracle):
     exp = oracle.find_peaks(y, 0.13, 0, cap=100)
     got = as_tuples(gpu.find_peaks(y, 0.13))
     assert got == exp and len(got) == 3
+
+
+@pytest.mark.parametrize("n", [1500, 1537, 1800, 2046, 2047, 2049, 3000])
+def test_chunks_between_one_and_two_tiles(gpu, oracle, n):
+    """Score arrays of 1.5 .. 3 k samples: with or without a full 1024-score tile inside, the
+    head / tail pieces are longer than the LDS window and go in slices."""
+    rng = np.random.default_rng(n)
+    y = (rng.uniform(-1, 1, n) + 0.8 * np.sin(np.arange(n) / 37.0)).astype(np.float32)
+    for prom, dist in ((0.0, 0), (0.3, 0), (0.3, 25), (0.9, 5000)):
+        exp = oracle.find_peaks(y, prom, dist, cap=4096)
+        if len(exp) > 1000:
+            continue
+        got = gpu.find_peaks(y, prom, dist)
+        assert [(g.start, g.end, g.height, g.prominence) for g in got] == [tuple(e) for e in exp], (n, prom, dist)
