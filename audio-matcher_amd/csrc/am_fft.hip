@@ -979,7 +979,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 // keeps the register footprint and occupancy of the 2^21 kernel) and therefore
 // reads both row halves; the two workgroups of a tile pair are adjacent on one XCD,
 // so the second read of a line is served by that L2.
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 3)
 k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     __shared__ K3Shared sh;
@@ -999,32 +999,14 @@ k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
     wd0 = make_float2(sgn * wd0.x, -sgn * wd0.y);   // +-conj(W_16384^m)
     wd1 = make_float2(sgn * wd1.x, -sgn * wd1.y);
-    // The e rows are requested as a whole, the o rows two at a time and folded in as they
-    // arrive: at most 16 + 2 sixteen-byte loads are in flight per thread, which keeps the kernel
-    // within 128 VGPRs -- four workgroups per CU like the 2^21 kernel (K3 is latency-bound: its
-    // time follows the number of resident workgroups; with all 32 loads in flight it needed 162
-    // VGPRs, three workgroups per CU, and 0.203 ms per 1 h haystack).
     float2 x0[16], x1[16];
     const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + m_0) + cp;
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) {
-        const float4 ve = in4[(2 * (size_t)(hi + 16 * bp)) * (kN2 / 2)];
-        x0[bp] = make_float2(ve.x, ve.y);
-        x1[bp] = make_float2(ve.z, ve.w);
-    }
-#pragma unroll
-    for (int part = 0; part < 8; ++part) {
-        float4 vo[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) vo[j] = in4[(2 * (size_t)(hi + 16 * (part * 2 + j)) + 1) * (kN2 / 2)];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int bp = part * 2 + j;
-            x0[bp] = cadd(x0[bp], cmul(make_float2(vo[j].x, vo[j].y), wd0));
-            x1[bp] = cadd(x1[bp], cmul(make_float2(vo[j].z, vo[j].w), wd1));
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        const size_t k1 = (size_t)(hi + 16 * bp);
+        const float4 ve = in4[(2 * k1) * (kN2 / 2)], vo = in4[(2 * k1 + 1) * (kN2 / 2)];
+        x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
+        x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
     }
     k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
 }
