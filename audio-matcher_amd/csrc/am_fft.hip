@@ -781,11 +781,6 @@ __device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, lo
     return mod_recip(hi2, c, inv_c) <= 31;
 }
 
-// small block-shared state of K3's fused scan
-struct K3Shared {
-    int vote[2];
-};
-
 // K3: conjugate twiddle, inverse 256-point column FFTs, scaling (scale_slice,
 // audio_matcher.rs:246-252, 306-308), crop to the block's valid lags
 // (centered(), :460-464) and the per-32-score (min,max) summary.
@@ -794,14 +789,12 @@ struct K3Shared {
 // b' order, columns col, col+1) are in registers: conjugate pipeline twiddle,
 // inverse 256-point column FFT, scaling, fused score scan, conditional raw-score
 // store.  Output index of row n1, column c is n1 * out_stride + c.
-__device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2, K3Shared* sh,
+__device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2,
                                         int n2_0, int out_stride, int t, long long blkA, long long blkB,
                                         float out_scale, float2 (&x0)[16], float2 (&x1)[16]) {
     const int hi = t >> 4, cp = t & 15;
     const long long N = 1ll << pl.logN;
     const long long col = n2_0 + 2 * cp;
-    int* vote = sh->vote;
-    if (t < 2) vote[t] = 0;
     // Chunk edges (scores i*c and i*c + d, audio_matcher.rs:104, 119).  With chunks longer
     // than a block (the usual case) each block holds at most one edge of either kind;
     // their positions depend on the block only and are worked out here, while the
@@ -894,14 +887,22 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
             edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
             edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         }
-        // one block-wide vote for both blocks: per-wave ballots into two LDS words
-        // (zeroed before the exchange barriers above)
+        // one block-wide vote for both blocks: every wavefront leaves its two ballots in the first
+        // words of a scan row of its own (its lanes are done reading it: the reads above were
+        // waited for before rmx could be compared), so the kernel needs no LDS beyond the 32 KB tile
         const bool pa = (leftA > 0 && rmxA >= scan.theta) || edgeA, pb = (leftB > 0 && rmxB >= scan.theta) || edgeB;
-        if (__ballot(pa) && (t & 63) == 0) vote[0] = 1;
-        if (__ballot(pb) && (t & 63) == 0) vote[1] = 1;
+        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+        int* votes = reinterpret_cast<int*>(lds2 + scan_row_of(t & ~63) * 16);   // row of the wave's lane 0
+        wave_sync_lds();
+        if ((t & 63) == 0) { votes[0] = ba != 0ull; votes[1] = bb != 0ull; }
         __syncthreads();
-        wantA = vote[0] != 0;
-        wantB = vote[1] != 0;
+        wantA = false; wantB = false;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int* v = reinterpret_cast<const int*>(lds2 + scan_row_of(w * 64) * 16);
+            wantA = wantA || v[0] != 0;
+            wantB = wantB || v[1] != 0;
+        }
         if (t == 0 && scan.wflags != nullptr) {
             const unsigned tile = (unsigned)n2_0 >> kColsLog;
             scan.wflags[blkA * (out_stride >> kColsLog) + tile] = wantA ? 1 : 0;
@@ -936,11 +937,13 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     }
 }
 
+#ifndef AM_K3_WGS
+#define AM_K3_WGS 3   // minimum workgroups per CU the register allocation has to allow (it uses 118 VGPRs: four fit)
+#endif
 template <bool HALF>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, AM_K3_WGS)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
-    __shared__ K3Shared sh;
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     // XCD-aware placement (speed only): the 16 adjacent column tiles that share
@@ -969,7 +972,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
             x1[bp] = make_float2(v.z, v.w);
         }
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
@@ -982,7 +985,6 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 __global__ void __launch_bounds__(256, 3)
 k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
-    __shared__ K3Shared sh;
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
@@ -1008,7 +1010,7 @@ k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
         x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), &sh, m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
