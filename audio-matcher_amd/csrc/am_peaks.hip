@@ -282,8 +282,14 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 // maxima with flat tops whose height can qualify, then their prominence.
 //
 // The piece and a halo of kHalo scores on either side are staged in LDS first (as
-// score_for_min sees them: raw where written, the run's exact minimum elsewhere).  A
-// candidate is then settled as cheaply as possible, in three stages of growing cost:
+// score_for_min sees them: raw where written, the run's exact minimum elsewhere), and with
+// them the (min, max) of every 32-score run of the window.  A candidate is then settled as
+// cheaply as possible, in stages of growing cost:
+//   0. the run summaries: a strictly higher score in the candidate's own run or in one of the
+//      next runs, with the minimum over the runs passed on the way less than min_prom below the
+//      candidate, rejects it after one to three 8-byte LDS reads (for a score array whose
+//      wiggles are smaller than min_prom that is every candidate that is not its run's maximum,
+//      and most that are);
 //   1. its own thread looks kNear scores to either side.  A score array that is not white
 //      has a local maximum every few scores (noise on top of whatever moves slowly), and for
 //      almost all of them a strictly higher score lies a few positions away, before the
@@ -300,6 +306,7 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 constexpr int kHalo = 256;
 constexpr int kNear = 32;
 constexpr int kWin = kTile + 2 * kHalo;
+constexpr int kWinRuns = kWin / 32 + 1;   // 32-score runs (aligned to absolute multiples of 32) a window can touch
 
 struct ChunkView {
     const float* g;
@@ -352,8 +359,8 @@ __device__ __forceinline__ bool side_scan_wave(const float* win, int from, int e
 }
 
 template <class Emit>
-__device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, float* win, Cand* queue, int qcap, int* queue_n,
-                           int* overflow, int tid, Emit emit) {
+__device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, float* win, float2* wruns, Cand* queue, int qcap,
+                           int* queue_n, int* overflow, int tid, Emit emit) {
     const int lane = tid & 63, wv = tid >> 6;
     const long long a = cv.a, b = cv.b;
     // window [w_lo, w_hi) = piece + halo, clipped to the chunk
@@ -361,6 +368,21 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
     const long long w_hi = hi + kHalo < b ? hi + kHalo : b;
     const int wn = (int)(w_hi - w_lo);
     for (long long i = w_lo + tid; i < w_hi; i += kPeakThreads) win[i - w_lo] = score_for_min(cv.g, cv.sp, i);
+    __syncthreads();
+    // (min, max) of every 32-score run the window touches (over the part inside the window): eight
+    // lanes per run, four scores each
+    const long long rb0 = w_lo >> 5;
+    const int nr = (int)(((w_hi - 1) >> 5) - rb0) + 1;
+    for (int r = tid >> 3; r < nr; r += kPeakThreads >> 3) {
+        const long long base = ((rb0 + r) << 5) + (tid & 7) * 4;
+        float mn = FLT_MAX, mx = -FLT_MAX;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (base + q >= w_lo && base + q < w_hi) { const float v = win[base + q - w_lo]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+        if ((tid & 7) == 0) wruns[r] = make_float2(mn, mx);
+    }
     __syncthreads();
     for (long long i = lo + tid; i < hi; i += kPeakThreads) {
         if (i <= a || i >= b - 1) continue;
@@ -372,6 +394,34 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
         long long k = i + 1;
         while (k < b - 1 && (k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) == x) ++k;
         if (!((k < w_hi ? win[k - w_lo] : score_for_cmp(cv.g, cv.sp, k)) < x)) continue;
+        // stage 0: the run summaries.  A strictly higher score that can be reached before the scores
+        // have dropped by min_prom settles the candidate against it, and both facts can be read off
+        // whole runs: run maxima say where a higher score is, and the minimum over the runs passed
+        // on the way (the candidate's own run included) bounds the minimum of the path from below.
+        // Rejections only; everything else goes on to the exact stages.
+        {
+            const int R = (int)((i >> 5) - rb0);
+            const float2 own = wruns[R];
+            bool rejected = false;
+            if (!((x - own.x) >= cv.min_prom)) {
+                rejected = own.y > x;
+                float acc = own.x;
+                for (int d = 1; !rejected && d <= 8 && R + d < nr; ++d) {
+                    const float2 st = wruns[R + d];
+                    acc = fminf(acc, st.x);
+                    if ((x - acc) >= cv.min_prom) break;
+                    rejected = st.y > x;
+                }
+                acc = own.x;
+                for (int d = 1; !rejected && d <= 8 && R - d >= 0; ++d) {
+                    const float2 st = wruns[R - d];
+                    acc = fminf(acc, st.x);
+                    if ((x - acc) >= cv.min_prom) break;
+                    rejected = st.y > x;
+                }
+            }
+            if (rejected) continue;
+        }
         // stage 1: flat-topped maximum [i, k) of height x against its kNear neighbours on either side
         // (a side is settled by a strictly higher score, or by the chunk edge)
         if (k <= w_hi) {
@@ -500,6 +550,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ int cand_n;
     __shared__ int kept_s, spill_off_s;
     __shared__ float win[kWin];
+    __shared__ float2 wruns[kWinRuns];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Segment sg = segs[blockIdx.x];
@@ -658,7 +709,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         // (a chunk without a full tile inside has a head piece of up to 2 * kTile - 2 scores:
         // the LDS window holds kTile + halo, so long pieces go in slices)
         for (long long q0 = lo; q0 < hi; q0 += kTile)
-            scan_piece(cv, q0, q0 + kTile < hi ? q0 + kTile : hi, win, queue, kQueueCap, &queue_n, &overflow, tid, emit);
+            scan_piece(cv, q0, q0 + kTile < hi ? q0 + kTile : hi, win, wruns, queue, kQueueCap, &queue_n, &overflow, tid, emit);
     }
     const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
     finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid);
@@ -674,6 +725,7 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
     __shared__ int queue_n;
     __shared__ int overflow;
     __shared__ float win[kWin];
+    __shared__ float2 wruns[kWinRuns];
     const int seg = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     if (wide.state[seg] != 1) return;
     const Segment sg = segs[seg];
@@ -697,12 +749,12 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
     };
     if (part == 0)
         for (long long q0 = a; q0 < head_hi; q0 += kTile)
-            scan_piece(cv, q0, q0 + kTile < head_hi ? q0 + kTile : head_hi, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
-    if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+            scan_piece(cv, q0, q0 + kTile < head_hi ? q0 + kTile : head_hi, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+    if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
     if (has_full)
         for (long long t = tf + part; t < tl; t += kWideParts) {
             if (!((stats[t].y - seg_min) >= min_prom)) continue;
-            scan_piece(cv, t * kTile, (t + 1) * kTile, win, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+            scan_piece(cv, t * kTile, (t + 1) * kTile, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
         }
     if (tid == 0 && overflow) atomicAdd(&wide.count[seg], (unsigned)AM_MAX_PEAKS_PER_CHUNK + 1u);   // poisons the count: reported as overflow
 }
