@@ -367,12 +367,33 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
     const long long w_lo = lo - kHalo > a ? lo - kHalo : a;
     const long long w_hi = hi + kHalo < b ? hi + kHalo : b;
     const int wn = (int)(w_hi - w_lo);
-    for (long long i = w_lo + tid; i < w_hi; i += kPeakThreads) win[i - w_lo] = score_for_min(cv.g, cv.sp, i);
+    // staging: which runs of the window were written is looked up once per run (K3 writes whole
+    // tiles, so a 32-score run is written or not as a whole); the scores then come in as
+    // independent loads, kWin / 256 per thread, with the unwritten runs filled from their minimum
+    const long long rb0 = w_lo >> 5;
+    const int nr = (int)(((w_hi - 1) >> 5) - rb0) + 1;
+    if (tid < nr) {
+        const long long first = ((rb0 + tid) << 5) > w_lo ? ((rb0 + tid) << 5) : w_lo;
+        const bool wr = run_written(cv.sp, first);
+        wruns[tid] = make_float2(wr ? 1.0f : 0.0f, wr ? 0.0f : cv.sp.stats32[first >> 5].x);
+    }
+    __syncthreads();
+    {
+        float v[kWin / kPeakThreads];
+#pragma unroll
+        for (int q = 0; q < kWin / kPeakThreads; ++q) {
+            const long long i = w_lo + tid + q * kPeakThreads;
+            v[q] = (i < w_hi && wruns[(i >> 5) - rb0].x != 0.0f) ? cv.g[i] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < kWin / kPeakThreads; ++q) {
+            const long long i = w_lo + tid + q * kPeakThreads;
+            if (i < w_hi) { const float2 f = wruns[(i >> 5) - rb0]; win[i - w_lo] = f.x != 0.0f ? v[q] : f.y; }
+        }
+    }
     __syncthreads();
     // (min, max) of every 32-score run the window touches (over the part inside the window): eight
     // lanes per run, four scores each
-    const long long rb0 = w_lo >> 5;
-    const int nr = (int)(((w_hi - 1) >> 5) - rb0) + 1;
     for (int r = tid >> 3; r < nr; r += kPeakThreads >> 3) {
         const long long base = ((rb0 + r) << 5) + (tid & 7) * 4;
         float mn = FLT_MAX, mx = -FLT_MAX;
