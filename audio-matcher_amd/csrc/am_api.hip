@@ -700,8 +700,9 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     }
     // one spare header behind the main ones serves the single-chunk passes below; the arena
     // holds every list of one haystack in the worst case plus a few entries per chunk
+    // (bounded: a chunk whose list finds no room is picked again on its own below)
     PeakArena arena{};
-    if ((rc = prepare_results(c, nsegs + 1, max_segs * AM_MAX_PEAKS_PER_CHUNK + nsegs * 8, &arena))) return rc;
+    if ((rc = prepare_results(c, nsegs + 1, std::min<size_t>(max_segs * AM_MAX_PEAKS_PER_CHUNK, (size_t)1 << 20) + nsegs * 8, &arena))) return rc;
     // the resident chunk list: the main-pass chunks, then one local slice [0, count) per
     // second-pass window (those are correlated on their own, see below)
     std::vector<Segment> resident = segs;
