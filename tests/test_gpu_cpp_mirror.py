@@ -1,5 +1,5 @@
-"""The C++ host mirror (include/audiomatch.hpp: CorrelateAlgo, HipConvolve, Config, calc_chunks with the
-reference's names, audio_matcher.rs:65-141) driven from a real C++ program on the GPU."""
+"""The C++ host mirror (include/audiomatch.hpp: CorrelateAlgo, HipConvolve, HipConvolvePool, Config, calc_chunks
+with the reference's names, audio_matcher.rs:65-141, matcher/mod.rs:42-87) driven from a real C++ program on the GPU."""
 import os
 import subprocess
 
@@ -35,6 +35,16 @@ int main(int argc, char** argv) {
     Config cfg; cfg.chunk_size = 10.0; cfg.overlap_length = 1.0; cfg.distance = 5.0; cfg.prominence = 0.13f;
     for (const Peak& p : calc_chunks(8000, hay.data(), hay.size(), algo, true, cfg))
         std::printf("peak %zu %zu %.9g %.9g\n", p.start, p.end, p.height, p.prominence);
+    // the file loop of matcher::run over the devices of the node (matcher/mod.rs:42-87)
+    HipConvolvePool pool(needle, {0, 0});
+    const std::vector<float> half(hay.begin(), hay.begin() + hay.size() / 2);
+    const std::vector<std::vector<Peak>> all = pool.calc_chunks(8000, {hay.data(), half.data(), hay.data()},
+                                                                {hay.size(), half.size(), hay.size()}, true, cfg);
+    std::printf("pool %zu", pool.size());
+    for (const auto& one : all) { std::printf(" |"); for (const Peak& p : one) std::printf(" %zu", p.start); }
+    std::printf("\n");
+    algo.set_option("log_n", 16);
+    std::printf("peaks16 %zu\n", calc_chunks(8000, hay.data(), hay.size(), algo, true, cfg).size());
     try { HipConvolve bad(std::vector<float>{}); } catch (const Error& e) { std::printf("error %d\n", e.code); }
     return 0;
 }
@@ -65,9 +75,12 @@ def test_cpp_mirror_program(gpu, oracle, tmp_path):
     assert int(n) == ref.size and abs(float(first) - ref[0]) < 1e-4 and abs(float(last) - ref[-1]) < 1e-4
     same = oracle.correlate(hay[:5000], needle, oracle.MODE_SAME, oracle.SCALE_LIB)
     assert int(out[2].split()[1]) == 5000 and abs(float(out[2].split()[2]) - same[1234]) < 1e-4
-    peaks = [l.split()[1:] for l in out if l.startswith("peak")]
+    peaks = [l.split()[1:] for l in out if l.startswith("peak ")]
     exp = oracle.calc_chunks(sr, hay, needle, 10 * sr, sr, 0.13, 5 * sr, 5.0)
     assert [(int(p[0]), int(p[1])) for p in peaks] == [(e[0], e[1]) for e in exp] == [(4 * sr, 4 * sr + 1), (17 * sr, 17 * sr + 1)]
     for p, e in zip(peaks, exp):
         assert abs(float(p[2]) - e[2]) < 1e-4 and abs(float(p[3]) - e[3]) < 1e-4
+    pool = [l for l in out if l.startswith("pool")][0]
+    assert pool == f"pool 2 | {4 * sr} {17 * sr} | {4 * sr} | {4 * sr} {17 * sr}"
+    assert [l for l in out if l.startswith("peaks16")] == ["peaks16 2"]
     assert out[-1] == "error 1"          # AM_ERR_INVALID_ARG surfaces as audiomatch::Error
