@@ -60,3 +60,39 @@ def test_shard_indices_partition():
         seen = sorted(k for r in range(world) for k in sharding.shard_indices(1000, r, world))
         assert seen == list(range(1000))
         assert all(sharding.owner_of(k, world) == r for r in range(world) for k in sharding.shard_indices(50, r, world))
+
+
+BENCH_WORKER = textwrap.dedent("""
+    import json, os, sys, types
+    sys.path.insert(0, %(root)r)
+    import bench
+    R = bench.Rank(types.SimpleNamespace(gpus=2))
+    R.init_dist()
+    R.barrier()
+    tmax = R.max_all(1.0 + R.rank)
+    parts = R.gather({"rank": R.rank, "mine": bench.shard(10, R.rank, R.world)})
+    if R.rank == 0:
+        print(json.dumps({"tmax": tmax, "parts": parts}))
+    R.close()
+""")
+
+
+def test_bench_control_plane_two_ranks(tmp_path):
+    """bench.py's rank plumbing (gloo barrier, MAX of the timed region, gather of per-rank
+    values, k mod N shard) with world_size 2 on the CPU -- the data path has no collective."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    import json
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert res["tmax"] == 2.0
+    assert res["parts"] == [{"rank": 0, "mine": [0, 2, 4, 6, 8]}, {"rank": 1, "mine": [1, 3, 5, 7, 9]}]
+    # a world size that disagrees with --gpus is refused before anything else happens
+    r = subprocess.run([sys.executable, "-c", "import sys, types; sys.path.insert(0, %r); import bench; bench.Rank(types.SimpleNamespace(gpus=4))" % ROOT],
+                       env=dict(env, RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
