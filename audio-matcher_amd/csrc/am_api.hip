@@ -694,7 +694,13 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                          c->ev_k3[0] && c->ev_k3[1] && c->ev_pick[0] && c->ev_pick[1];
     if ((rc = c->scores.ensure(max_scores * sizeof(float)))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+    // sized once for the longest haystack, so that no pick of the batch has to grow them while
+    // the previous pick still runs on the other stream
+    if ((rc = c->wide_ctl.ensure(max_segs * 12))) return rc;
+    if ((rc = c->wide_list.ensure(max_segs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    if ((rc = c->stats.ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
     if (overlap) {
+        if ((rc = c->stats_b.ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
         if ((rc = c->scores_b.ensure(max_scores * sizeof(float)))) return rc;
         if ((rc = c->peaks_b.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     }
