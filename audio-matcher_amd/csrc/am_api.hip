@@ -558,10 +558,11 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     }
     // hand-over area for chunks with many candidate tiles (per chunk of this launch; the picks
     // of one call run in stream order, so one area serves them all)
-    if ((rc = c->wide_ctl.ensure((size_t)nsegs * 12))) return rc;
+    if ((rc = c->wide_ctl.ensure((size_t)nsegs * 24))) return rc;
     if ((rc = c->wide_list.ensure((size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
     WideState wide{};
-    wide.state = static_cast<int*>(c->wide_ctl.p);
+    wide.best = static_cast<unsigned long long*>(c->wide_ctl.p);
+    wide.state = reinterpret_cast<int*>(wide.best + nsegs);
     wide.count = reinterpret_cast<unsigned*>(wide.state + nsegs);
     wide.seg_min = reinterpret_cast<float*>(wide.state + 2 * nsegs);
     wide.list = static_cast<am_peak*>(c->wide_list.p);
@@ -696,7 +697,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     if ((rc = c->peaks.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     // sized once for the longest haystack, so that no pick of the batch has to grow them while
     // the previous pick still runs on the other stream
-    if ((rc = c->wide_ctl.ensure(max_segs * 12))) return rc;
+    if ((rc = c->wide_ctl.ensure(max_segs * 24))) return rc;
     if ((rc = c->wide_list.ensure(max_segs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
     if ((rc = c->stats.ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
     if (overlap) {

@@ -116,6 +116,7 @@ struct WideState {
     int* state;          // 0 = finished by peaks_kernel, 1 = handed over
     unsigned* count;     // peaks appended to the chunk's list (> AM_MAX_PEAKS_PER_CHUNK: overflow)
     float* seg_min;
+    unsigned long long* best;   // min_distance >= chunk length: running maximum of the peaks that pass (order-preserving key)
     am_peak* list;
 };
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,

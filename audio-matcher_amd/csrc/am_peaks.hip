@@ -543,6 +543,48 @@ __device__ void finish_chunk(am_peak* res, int rn, int* order, int overflow, lon
     }
 }
 
+// min_distance >= chunk length (the reference's default): the distance filter keeps exactly the
+// first peak in (height descending, position ascending) order that passed the prominence filter,
+// so the general path does not have to list the peaks that pass (there can be tens of thousands
+// in a chunk whose scores ripple by more than min_prom) -- a running maximum over an order-
+// preserving key is enough, and nothing can overflow.  The winner's plateau end and prominence
+// are worked out again at the end (one scan, one walk).
+__device__ __forceinline__ unsigned long long best_key(float h, long long rel) {
+    unsigned u = __float_as_uint(h);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rel);
+}
+__device__ void finish_best(const ChunkView& cv, unsigned long long key, am_peak* my_out, SegHeader* hd,
+                            long long* pe_s, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    if (key == 0ull) {
+        if (tid == 0) { hd->n = 0; hd->overflow = 0; hd->seg_min = cv.seg_min; hd->arena_off = -1; }
+        return;
+    }
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    const float h = __uint_as_float(u);
+    const long long ps = cv.a + (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    if (tid == 0) {
+        long long k = ps + 1;
+        while (k < cv.b - 1 && score_for_cmp(cv.g, cv.sp, k) == h) ++k;
+        *pe_s = k;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        float prom = 0.0f;
+        const bool keep = prominence(cv.g, cv.stats, cv.sp, cv.a, cv.b, ps, *pe_s, h, cv.min_prom, lane, prom);
+        if (lane == 0) {
+            if (keep) {
+                am_peak pk; pk.start = (uint64_t)ps; pk.end = (uint64_t)*pe_s; pk.height = h; pk.prominence = prom;
+                hd->first[0] = pk;
+                my_out[0] = pk;
+            }
+            hd->n = keep ? 1 : 0; hd->overflow = 0; hd->seg_min = cv.seg_min; hd->arena_off = -1;
+        }
+    }
+}
+
 // Chunks whose general path would visit more than kWideTiles candidate tiles are not
 // finished by their one workgroup: peaks_kernel marks them in `wide` and the two kernels
 // behind it take over -- peaks_wide spreads a chunk's pieces over kWideParts workgroups that
@@ -572,12 +614,14 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ int kept_s, spill_off_s;
     __shared__ float win[kWin];
     __shared__ float2 wruns[kWinRuns];
+    __shared__ unsigned long long best_s;
+    __shared__ long long pe_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Segment sg = segs[blockIdx.x];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
-    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; wide.state[blockIdx.x] = 0; }
+    if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; best_s = 0ull; wide.state[blockIdx.x] = 0; }
     if (b - a < 3) {
         if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = 0.f; hdr[blockIdx.x].arena_off = -1; }
         return;
@@ -702,14 +746,16 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __syncthreads();
     if (cand_n > kWideTiles && wide.list != nullptr) {
         // too much for one workgroup: hand the chunk to peaks_wide / peaks_finish
-        if (tid == 0) { wide.seg_min[blockIdx.x] = seg_min; wide.count[blockIdx.x] = 0; wide.state[blockIdx.x] = 1; }
+        if (tid == 0) { wide.seg_min[blockIdx.x] = seg_min; wide.count[blockIdx.x] = 0; wide.best[blockIdx.x] = 0ull; wide.state[blockIdx.x] = 1; }
         return;
     }
     // more candidates than the list holds: visit every full tile instead
     const bool all_tiles = cand_n > kCandCap;
     const long long nmid = has_full ? (all_tiles ? (tl - tf) : cand_n) : 0;
     ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
+    const bool best_mode = min_dist >= b - a && b - a < 0xFFFFFFFFll;
     auto emit = [&](long long ps, long long pe, float h, float prom) {
+        if (best_mode) { atomicMax(&best_s, best_key(h, ps - a)); return; }
         const int slot = atomicAdd(&res_n, 1);
         if (slot < AM_MAX_PEAKS_PER_CHUNK) {
             res[slot].start = (uint64_t)ps; res[slot].end = (uint64_t)pe;
@@ -732,6 +778,10 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         for (long long q0 = lo; q0 < hi; q0 += kTile)
             scan_piece(cv, q0, q0 + kTile < hi ? q0 + kTile : hi, win, wruns, queue, kQueueCap, &queue_n, &overflow, tid, emit);
     }
+    if (best_mode) {
+        finish_best(cv, best_s, my_out, &hdr[blockIdx.x], &pe_s, tid);
+        return;
+    }
     const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
     finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid);
 }
@@ -741,7 +791,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
 // prominence filter to the chunk's list.
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
-           const Segment* __restrict__ segs, float min_prom, SparseScores sp, WideState wide) {
+           const Segment* __restrict__ segs, float min_prom, long long min_dist, SparseScores sp, WideState wide) {
     __shared__ Cand queue[kWideQueue];
     __shared__ int queue_n;
     __shared__ int overflow;
@@ -761,7 +811,9 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
     __syncthreads();
     ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
     am_peak* list = wide.list + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
+    const bool best_mode = min_dist >= b - a && b - a < 0xFFFFFFFFll;
     auto emit = [&](long long ps, long long pe, float h, float prom) {
+        if (best_mode) { atomicMax(&wide.best[seg], best_key(h, ps - a)); return; }
         const unsigned slot = atomicAdd(&wide.count[seg], 1u);
         if (slot < (unsigned)AM_MAX_PEAKS_PER_CHUNK) {
             am_peak pk; pk.start = (uint64_t)ps; pk.end = (uint64_t)pe; pk.height = h; pk.prominence = prom;
@@ -782,20 +834,30 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
 
 // grid nsegs: sort + distance filter of a chunk that went through peaks_wide
 __global__ void __launch_bounds__(kPeakThreads)
-peaks_finish(const Segment* __restrict__ segs, long long min_dist, am_peak* __restrict__ out,
-             SegHeader* __restrict__ hdr, PeakArena arena, WideState wide) {
+peaks_finish(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
+             const Segment* __restrict__ segs, float min_prom, long long min_dist, am_peak* __restrict__ out,
+             SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide) {
     __shared__ am_peak res[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int order[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int kept_s, spill_off_s;
+    __shared__ long long pe_s;
     const int seg = blockIdx.x, tid = threadIdx.x;
     if (wide.state[seg] != 1) return;
+    am_peak* my_out = out + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
+    const Segment sg = segs[seg];
+    const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
+    if (min_dist >= b - a && b - a < 0xFFFFFFFFll) {
+        ChunkView cv{g, stats, sp, a, b, wide.seg_min[seg], min_prom};
+        finish_best(cv, wide.best[seg], my_out, &hdr[seg], &pe_s, tid);
+        return;
+    }
     const unsigned cnt = wide.count[seg];
     const int rn = cnt < (unsigned)AM_MAX_PEAKS_PER_CHUNK ? (int)cnt : AM_MAX_PEAKS_PER_CHUNK;
     const am_peak* list = wide.list + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
     for (int i = tid; i < rn; i += kPeakThreads) res[i] = list[i];
     __syncthreads();
     finish_chunk(res, rn, order, cnt > (unsigned)AM_MAX_PEAKS_PER_CHUNK ? 1 : 0, min_dist, wide.seg_min[seg],
-                 out + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK, &hdr[seg], arena, &kept_s, &spill_off_s, tid);
+                 my_out, &hdr[seg], arena, &kept_s, &spill_off_s, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -884,8 +946,9 @@ hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const f
     if (wide.list != nullptr) {
         // both return at once for chunks that peaks_kernel finished itself (the usual case)
         hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                           min_prom, sp, wide);
-        hipLaunchKernelGGL(peaks_finish, dim3(nsegs), dim3(kPeakThreads), 0, st, d_segs, min_dist, d_out, d_hdr, arena, wide);
+                           min_prom, min_dist, sp, wide);
+        hipLaunchKernelGGL(peaks_finish, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs, min_prom, min_dist,
+                           d_out, d_hdr, sp, arena, wide);
     }
     return hipGetLastError();
 }

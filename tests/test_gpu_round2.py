@@ -449,3 +449,43 @@ def test_many_qualifying_maxima_small_distance(gpu, oracle):
         for _ in range(2):
             got = algo.match(hay, p, cap=1 << 16)
             assert_same(got, exp)
+
+
+def test_default_distance_with_thousands_of_qualifying_maxima(gpu, oracle):
+    """min_distance >= chunk (the reference's default regime) on a score array whose ripple is
+    larger than min_prominence: about two thousand maxima per chunk pass the prominence filter --
+    more than any list holds -- and the distance filter keeps the tallest.  With a rising drift
+    the chunk's maximum sits at the chunk's end and fails the prominence test itself, so the
+    answer has to come from the general path (a running maximum, nothing to overflow)."""
+    sr = 8000
+    rng = np.random.default_rng(43)
+    s, h = 2 * sr, 200 * sr
+    t = np.arange(h, dtype=np.float64)
+    tone = (0.0827 * np.sin(2 * np.pi * 50.0 / sr * t)).astype(np.float32)      # score ripple about +-0.1
+    drift = (0.04 * np.sin(2 * np.pi * t / (160.0 * sr))).astype(np.float32)
+    needle = rng.uniform(-0.25, 0.25, s).astype(np.float32) + tone[:s] + np.float32(0.1)
+    hay = rng.uniform(-0.25, 0.25, h).astype(np.float32) + tone + drift
+    hay[int(95.0 * sr) + 7:int(95.0 * sr) + 7 + s] += needle
+    cfg = gpu.Config(chunk_size_s=40.0, overlap_length_s=2.0, distance_s=45.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 45.0)
+    sc = oracle.correlate(hay[: 42 * sr], needle, oracle.MODE_VALID, oracle.SCALE_LIB)
+    assert len(oracle.find_peaks(sc, 0.13, 0, cap=1 << 16)) > 1500        # far beyond AM_MAX_PEAKS_PER_CHUNK
+    assert len(exp) >= 2 and int(95.0 * sr) + 7 in [e[0] for e in exp]
+    algo = gpu.HipConvolve(needle)
+    for _ in range(2):
+        assert_same(algo.match(hay, p), exp)
+    # The hard case made on purpose, through find_peaks on a given score array: a steep ramp under
+    # the ripple, cut off 20 scores behind a crest.  The array's maximum is that last crest, whose
+    # right side ends at the edge before it has dropped by min_prominence: it fails, about two
+    # thousand others pass, and the answer is the tallest of those.
+    for seed in range(3):
+        n = 160 * 2000 + 60
+        tt = np.arange(n, dtype=np.float64)
+        y = (2e-5 * tt + 0.1 * np.sin(2 * np.pi * tt / 160.0) +
+             0.002 * np.random.default_rng(seed).standard_normal(n)).astype(np.float32)
+        ref = oracle.find_peaks(y, 0.13, n)
+        assert len(oracle.find_peaks(y, 0.13, 0, cap=1 << 16)) > 1500 and len(ref) == 1
+        assert ref[0][0] < n - 100                                          # not the last crest
+        got = gpu.find_peaks(y, 0.13, n)
+        assert [(g.start, g.end, g.height, g.prominence) for g in got] == [tuple(r) for r in ref]
