@@ -33,7 +33,7 @@ enum {
     AM_ERR_CAPACITY = 2,      /* caller buffer too small; required length was written */
     AM_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed */
     AM_ERR_NO_DEVICE = 4,     /* no gfx950-capable device / bad ordinal */
-    AM_ERR_PEAK_OVERFLOW = 5, /* more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk */
+    AM_ERR_PEAK_OVERFLOW = 5, /* more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk (see there) */
     AM_ERR_OOM = 6            /* host or device allocation failed */
 };
 
@@ -49,7 +49,9 @@ enum { AM_MODE_FULL = 0, AM_MODE_SAME = 1, AM_MODE_VALID = 2 };
  *                                                  audio_matcher.rs:442-448 */
 enum { AM_SCALE_NONE = 0, AM_SCALE_LIB = 1, AM_SCALE_MY = 2 };
 
-/* Upper bound on peaks that pass the prominence filter inside ONE chunk. */
+/* Upper bound on peaks that pass the prominence filter inside ONE chunk when min_distance is
+ * shorter than the chunk (with min_distance >= chunk length, the reference's default, the
+ * distance filter keeps the tallest of however many pass and no bound applies). */
 #define AM_MAX_PEAKS_PER_CHUNK 1024
 
 /* Opaque handle = the reference's `LibConvolve { sample_data, .. }` /
