@@ -243,7 +243,12 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     if (logN1 > 9) logN1 = 9;
     int logN2 = logN - logN1;
     // N = 2^22 runs on the register kernels as 256 columns x two 8192-point row halves
-    const int wide = logN == 22 ? 1 : 0;
+    // (AM_PLAN22_W16 = 1 selects the older form of this plan: rows split by one radix-2 stage
+    // into halves, 256-thread column kernels that handle two tiles; kept for A/B measurements)
+#ifndef AM_PLAN22_W16
+#define AM_PLAN22_W16 0
+#endif
+    const int wide = (logN == 22 && AM_PLAN22_W16) ? 1 : 0;
     if (wide) { logN1 = 8; logN2 = 13; }
     const int logLo = (logN + 1) / 2;
     const size_t n1h = (size_t)1 << (logN1 - 1), n2h = (size_t)1 << (logN2 - 1);
@@ -418,7 +423,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     if (scan_req) {
         scan_req->fused = false;
         scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
-        if (plan_is_r16(pl->dev) && (hop % kTile) == 0) {
+        if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
             DevBuf& b32 = scan_req->set ? c->stats32_b : c->stats32;
             DevBuf& bwf = scan_req->set ? c->wflags_b : c->wflags;
             if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
@@ -868,7 +873,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     if ((rc = prepare_results(c, (size_t)nsegs * nn, (size_t)nsegs * nn * 8 + 4096, &arena))) return rc;
     if ((rc = upload_segments(c, segs))) return rc;
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
-    const bool fused = plan_is_r16(pl->dev) && (hop % kTile) == 0;
+    const bool fused = plan_has_scan(pl->dev) && (hop % kTile) == 0;
     if (fused) {
         if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
         if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;

@@ -716,25 +716,31 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // The column owner (hi, cp) holds rows a*16 + hi, a = 0..15, and a wavefront holds four
 // values of hi, so the 32 scores of a row are written by 16 lanes of ONE wavefront.  The row is
 // therefore read back by a lane of that same wavefront -- lane l of wave w takes row
-// r = (l >> 2) * 16 + 4 w + (l & 3) -- and the exchange needs no workgroup barrier, only the
+// r = (l >> 2) * 16 + 4 w + (l & 3) (* 32 in the 512-row kernels) -- and the exchange needs no workgroup barrier, only the
 // wavefront's own ordering (wave_sync_lds).  16-byte chunk c of row r sits at chunk position
-// c ^ s(r), s(r) = ((r >> 4) & 3) << 1 | ((r & 3) >> 1): with it both the 8-byte writes of the
+// c ^ s(r), s(r) = (a & 3) << 1 | ((r & 3) >> 1), a = the row's register index: with it both the 8-byte writes of the
 // column owners and the 16-byte reads of the row owners are conflict-free (every 16-lane group
 // of a ds_read_b128 meets all 16 chunk columns once).
-__device__ __forceinline__ unsigned scan_swizzle(unsigned row) { return (((row >> 4) & 3u) << 1) | ((row & 3u) >> 1); }
-__device__ __forceinline__ int scan_row_of(int t) { return ((t & 63) >> 2) * 16 + (t >> 6) * 4 + (t & 3); }
+// HB = log2 of the number of hi values (rows per register index a): 4 for the 256-row kernels
+// (256 threads), 5 for the 512-row ones (512 threads).  Row = a * 2^HB + hi.
+template <int HB>
+__device__ __forceinline__ unsigned scan_swizzle(unsigned row) { return (((row >> HB) & 3u) << 1) | ((row & 3u) >> 1); }
+template <int HB>
+__device__ __forceinline__ int scan_row_of(int t) { return ((t & 63) >> 2) * (1 << HB) + (t >> 6) * 4 + (t & 3); }
+template <int HB>
 __device__ __forceinline__ void scan_put(float2* lds2, int hi, int cp, const float (&c0)[16], const float (&c1)[16]) {
     const unsigned half = (unsigned)cp & 1u, chunk = (unsigned)cp >> 1, hb = ((unsigned)hi & 3u) >> 1;
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         const unsigned pos = chunk ^ ((((unsigned)a & 3u) << 1) | hb);
-        lds2[a * 256 + hi * 16 + (int)((pos << 1) | half)] = make_float2(c0[a], c1[a]);
+        lds2[a * (16 << HB) + hi * 16 + (int)((pos << 1) | half)] = make_float2(c0[a], c1[a]);
     }
 }
 // row = the run's row; whole = every score of the run is valid, otherwise scores at run offsets
 // >= nvalid are ignored
+template <int HB>
 __device__ __forceinline__ void scan_row_minmax(const float4* lds4, int row, bool whole, int nvalid, float& mn, float& mx) {
-    const unsigned k = scan_swizzle((unsigned)row);
+    const unsigned k = scan_swizzle<HB>((unsigned)row);
     float4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = lds4[row * 8 + (int)((unsigned)i ^ k)];
@@ -789,32 +795,150 @@ __device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, lo
 // b' order, columns col, col+1) are in registers: conjugate pipeline twiddle,
 // inverse 256-point column FFT, scaling, fused score scan, conditional raw-score
 // store.  Output index of row n1, column c is n1 * out_stride + c.
+struct K3Edges {
+    long long outA, outB, ecA, edA, ecB, edB;
+    bool one_edge;
+};
+// Chunk edges (scores i*c and i*c + d, audio_matcher.rs:104, 119).  With chunks longer
+// than a block (the usual case) each block holds at most one edge of either kind;
+// their positions depend on the block only and are worked out while the tile's loads
+// are still in flight.
+__device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan, long long blkA, long long blkB) {
+    K3Edges e;
+    e.outA = blkA * job.hop; e.outB = blkB * job.hop;
+    e.one_edge = scan.stats32 != nullptr && scan.seg_c >= (long long)job.hop + 32;
+    e.ecA = 0; e.edA = 0; e.ecB = 0; e.edB = 0;
+    if (e.one_edge) {
+        const long long c = scan.seg_c, d = scan.seg_d;
+        const long long m = mod_recip(e.outA, c, scan.inv_c);
+        e.ecA = m == 0 ? e.outA : e.outA + (c - m);      // smallest i*c >= outA
+        e.edA = d;                                       // smallest i*c + d >= outA, i >= 0
+        if (e.outA > d) {
+            const long long m2 = mod_recip(e.outA - d, c, scan.inv_c);
+            e.edA = m2 == 0 ? e.outA : e.outA + (c - m2);
+        }
+        // block B starts hop < c later: its first edge is the same one or the next
+        e.ecB = e.ecA >= e.outB ? e.ecA : e.ecA + c;
+        e.edB = e.edA >= e.outB ? e.edA : e.edA + c;
+    }
+    return e;
+}
+
+// The end of K3 for one column tile: x0 / x1[brev(a)] hold the correlation values of rows
+// n1 = a * 2^HB + hi (columns col, col+1; real part = block A, imaginary part = block B):
+// scaling, fused score scan, block vote, conditional raw-score store.
+template <int HB>
+__device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, const K3Edges& ed, float2* lds2,
+                                          int n2_0, int out_stride, int t, long long blkA, long long blkB,
+                                          float out_scale, const float2 (&x0)[16], const float2 (&x1)[16]) {
+    const int hi = t >> 4, cp = t & 15;
+    const long long col = n2_0 + 2 * cp;
+    const long long outA = ed.outA, outB = ed.outB, ecA = ed.ecA, edA = ed.edA, ecB = ed.ecB, edB = ed.edB;
+    const bool one_edge = ed.one_edge;
+    const bool dst8 = ((reinterpret_cast<uintptr_t>(job.dst) & 7) == 0) && ((job.hop & 1) == 0);
+    long long limA = job.out_count - outA; if (limA > job.hop) limA = job.hop;
+    long long limB = blkB < job.nblocks ? job.out_count - outB : 0; if (limB > job.hop) limB = job.hop;
+    // scores of row n1 = a*16 + hi: block A columns col, col+1 = (sa0, sa1), block B = (sb0, sb1)
+    float sa0[16], sa1[16], sb0[16], sb1[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const float2 v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
+        sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
+        sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
+    }
+    bool wantA = true, wantB = true;
+    if (scan.stats32 != nullptr) {
+        // ---- fused score scan: (min,max) per 32 consecutive scores ------------
+        // this thread owns the run of row n1 = row (scores row*out_stride + n2_0 .. +31 of both blocks)
+        const int row = scan_row_of<HB>(t);
+        const long long rowrun = (long long)row * out_stride + n2_0;
+        // Every run is wholly valid or wholly invalid, except in the block that holds
+        // the end of the score array.
+        const long long leftA = limA - rowrun, leftB = limB - rowrun;
+        const bool wholeA = leftA >= 32 || leftA <= 0, wholeB = leftB >= 32 || leftB <= 0;
+        const float4* lds4 = reinterpret_cast<const float4*>(lds2);
+        float rmnA, rmxA, rmnB, rmxB;
+        __syncthreads();   // the column exchange above is finished with the tile (it crosses wavefronts)
+        scan_put<HB>(lds2, hi, cp, sa0, sa1);
+        wave_sync_lds();   // a row is written and read by lanes of one wavefront
+        scan_row_minmax<HB>(lds4, row, wholeA, (int)(leftA < 32 ? leftA : 32), rmnA, rmxA);
+        wave_sync_lds();
+        scan_put<HB>(lds2, hi, cp, sb0, sb1);
+        wave_sync_lds();
+        scan_row_minmax<HB>(lds4, row, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
+        // raw scores leave the chip only for tiles that can matter to the peak
+        // pick: some score >= theta, or a run that straddles a chunk edge
+        bool edgeA, edgeB;
+        if (one_edge) {
+            const unsigned long long loA = (unsigned long long)(outA + rowrun), loB = (unsigned long long)(outB + rowrun);
+            edgeA = leftA > 0 && ((unsigned long long)ecA - loA <= 31ull || (unsigned long long)edA - loA <= 31ull);
+            edgeB = leftB > 0 && ((unsigned long long)ecB - loB <= 31ull || (unsigned long long)edB - loB <= 31ull);
+        } else {
+            edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+            edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
+        }
+        // one block-wide vote for both blocks: every wavefront leaves its two ballots in the first
+        // words of a scan row of its own (its lanes are done reading it: the reads above were
+        // waited for before rmx could be compared), so the kernel needs no LDS beyond the 32 KB tile
+        const bool pa = (leftA > 0 && rmxA >= scan.theta) || edgeA, pb = (leftB > 0 && rmxB >= scan.theta) || edgeB;
+        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+        int* votes = reinterpret_cast<int*>(lds2 + scan_row_of<HB>(t & ~63) * 16);   // row of the wave's lane 0
+        wave_sync_lds();
+        if ((t & 63) == 0) { votes[0] = ba != 0ull; votes[1] = bb != 0ull; }
+        __syncthreads();
+        wantA = false; wantB = false;
+#pragma unroll
+        for (int w = 0; w < (1 << (HB - 2)); ++w) {
+            const int* v = reinterpret_cast<const int*>(lds2 + scan_row_of<HB>(w * 64) * 16);
+            wantA = wantA || v[0] != 0;
+            wantB = wantB || v[1] != 0;
+        }
+        if (t == 0 && scan.wflags != nullptr) {
+            const unsigned tile = (unsigned)n2_0 >> kColsLog;
+            scan.wflags[blkA * (out_stride >> kColsLog) + tile] = wantA ? 1 : 0;
+            if (blkB < job.nblocks) scan.wflags[blkB * (out_stride >> kColsLog) + tile] = wantB ? 1 : 0;
+        }
+        if (leftA > 0) scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
+        if (leftB > 0) scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
+    }
+    if (wantA) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
+            // hop and out offsets are even whenever this kernel is used, so a pair is
+            // valid or invalid as a whole except at the very end of the score array
+            if (dst8 && n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(sa0[a], sa1[a]);
+            else {
+                if (n < limA) job.dst[outA + n] = sa0[a];
+                if (n + 1 < limA) job.dst[outA + n + 1] = sa1[a];
+            }
+        }
+    }
+    if (wantB) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
+            if (dst8 && n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(sb0[a], sb1[a]);
+            else {
+                if (n < limB) job.dst[outB + n] = sb0[a];
+                if (n + 1 < limB) job.dst[outB + n + 1] = sb1[a];
+            }
+        }
+    }
+}
+
+
+// k3_tile: everything the 256-row K3 kernels do with one column tile once its rows
+// k1 = hi + 16*b' (natural b' order, columns col, col+1) are in registers: conjugate
+// pipeline twiddle, inverse 256-point column FFT, then k3_finish.  Output index of row n1,
+// column c is n1 * out_stride + c.
 __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2,
                                         int n2_0, int out_stride, int t, long long blkA, long long blkB,
                                         float out_scale, float2 (&x0)[16], float2 (&x1)[16]) {
     const int hi = t >> 4, cp = t & 15;
     const long long N = 1ll << pl.logN;
     const long long col = n2_0 + 2 * cp;
-    // Chunk edges (scores i*c and i*c + d, audio_matcher.rs:104, 119).  With chunks longer
-    // than a block (the usual case) each block holds at most one edge of either kind;
-    // their positions depend on the block only and are worked out here, while the
-    // tile's loads are still in flight.
-    const long long outA = blkA * job.hop, outB = blkB * job.hop;
-    const bool one_edge = scan.stats32 != nullptr && scan.seg_c >= (long long)job.hop + 32;
-    long long ecA = 0, edA = 0, ecB = 0, edB = 0;
-    if (one_edge) {
-        const long long c = scan.seg_c, d = scan.seg_d;
-        const long long m = mod_recip(outA, c, scan.inv_c);
-        ecA = m == 0 ? outA : outA + (c - m);            // smallest i*c >= outA
-        edA = d;                                         // smallest i*c + d >= outA, i >= 0
-        if (outA > d) {
-            const long long m2 = mod_recip(outA - d, c, scan.inv_c);
-            edA = m2 == 0 ? outA : outA + (c - m2);
-        }
-        // block B starts hop < c later: its first edge is the same one or the next
-        ecB = ecA >= outB ? ecA : ecA + c;
-        edB = edA >= outB ? edA : edA + c;
-    }
+    const K3Edges ed = k3_edges(job, scan, blkA, blkB);
     const unsigned maskN = (unsigned)(N - 1);
     const float2 w256 = pl.tw1[hi];
     {
@@ -845,96 +969,7 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     twiddle_nat<16, true>(x1, w256);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
-    const bool dst8 = ((reinterpret_cast<uintptr_t>(job.dst) & 7) == 0) && ((job.hop & 1) == 0);
-    long long limA = job.out_count - outA; if (limA > job.hop) limA = job.hop;
-    long long limB = blkB < job.nblocks ? job.out_count - outB : 0; if (limB > job.hop) limB = job.hop;
-    // scores of row n1 = a*16 + hi: block A columns col, col+1 = (sa0, sa1), block B = (sb0, sb1)
-    float sa0[16], sa1[16], sb0[16], sb1[16];
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        const float2 v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
-        sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
-        sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
-    }
-    bool wantA = true, wantB = true;
-    if (scan.stats32 != nullptr) {
-        // ---- fused score scan: (min,max) per 32 consecutive scores ------------
-        // this thread owns the run of row n1 = row (scores row*out_stride + n2_0 .. +31 of both blocks)
-        const int row = scan_row_of(t);
-        const long long rowrun = (long long)row * out_stride + n2_0;
-        // Every run is wholly valid or wholly invalid, except in the block that holds
-        // the end of the score array.
-        const long long leftA = limA - rowrun, leftB = limB - rowrun;
-        const bool wholeA = leftA >= 32 || leftA <= 0, wholeB = leftB >= 32 || leftB <= 0;
-        const float4* lds4 = reinterpret_cast<const float4*>(lds2);
-        float rmnA, rmxA, rmnB, rmxB;
-        __syncthreads();   // the column exchange above is finished with the tile (it crosses wavefronts)
-        scan_put(lds2, hi, cp, sa0, sa1);
-        wave_sync_lds();   // a row is written and read by lanes of one wavefront
-        scan_row_minmax(lds4, row, wholeA, (int)(leftA < 32 ? leftA : 32), rmnA, rmxA);
-        wave_sync_lds();
-        scan_put(lds2, hi, cp, sb0, sb1);
-        wave_sync_lds();
-        scan_row_minmax(lds4, row, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
-        // raw scores leave the chip only for tiles that can matter to the peak
-        // pick: some score >= theta, or a run that straddles a chunk edge
-        bool edgeA, edgeB;
-        if (one_edge) {
-            const unsigned long long loA = (unsigned long long)(outA + rowrun), loB = (unsigned long long)(outB + rowrun);
-            edgeA = leftA > 0 && ((unsigned long long)ecA - loA <= 31ull || (unsigned long long)edA - loA <= 31ull);
-            edgeB = leftB > 0 && ((unsigned long long)ecB - loB <= 31ull || (unsigned long long)edB - loB <= 31ull);
-        } else {
-            edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
-            edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
-        }
-        // one block-wide vote for both blocks: every wavefront leaves its two ballots in the first
-        // words of a scan row of its own (its lanes are done reading it: the reads above were
-        // waited for before rmx could be compared), so the kernel needs no LDS beyond the 32 KB tile
-        const bool pa = (leftA > 0 && rmxA >= scan.theta) || edgeA, pb = (leftB > 0 && rmxB >= scan.theta) || edgeB;
-        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
-        int* votes = reinterpret_cast<int*>(lds2 + scan_row_of(t & ~63) * 16);   // row of the wave's lane 0
-        wave_sync_lds();
-        if ((t & 63) == 0) { votes[0] = ba != 0ull; votes[1] = bb != 0ull; }
-        __syncthreads();
-        wantA = false; wantB = false;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int* v = reinterpret_cast<const int*>(lds2 + scan_row_of(w * 64) * 16);
-            wantA = wantA || v[0] != 0;
-            wantB = wantB || v[1] != 0;
-        }
-        if (t == 0 && scan.wflags != nullptr) {
-            const unsigned tile = (unsigned)n2_0 >> kColsLog;
-            scan.wflags[blkA * (out_stride >> kColsLog) + tile] = wantA ? 1 : 0;
-            if (blkB < job.nblocks) scan.wflags[blkB * (out_stride >> kColsLog) + tile] = wantB ? 1 : 0;
-        }
-        if (leftA > 0) scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
-        if (leftB > 0) scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
-    }
-    if (wantA) {
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * 16 + hi) * out_stride + col;
-            // hop and out offsets are even whenever this kernel is used, so a pair is
-            // valid or invalid as a whole except at the very end of the score array
-            if (dst8 && n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(sa0[a], sa1[a]);
-            else {
-                if (n < limA) job.dst[outA + n] = sa0[a];
-                if (n + 1 < limA) job.dst[outA + n + 1] = sa1[a];
-            }
-        }
-    }
-    if (wantB) {
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * 16 + hi) * out_stride + col;
-            if (dst8 && n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(sb0[a], sb1[a]);
-            else {
-                if (n < limB) job.dst[outB + n] = sb0[a];
-                if (n + 1 < limB) job.dst[outB + n + 1] = sb1[a];
-            }
-        }
-    }
+    k3_finish<4>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
 }
 
 #ifndef AM_K3_WGS
@@ -1011,6 +1046,176 @@ k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
     }
     k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
+}
+
+// ===========================================================================
+// N = 2^22 = 512 x 8192 without the row split: column kernels with 512 threads (two waves
+// per SIMD; two workgroups = 16 waves per CU, like the 256-thread kernels at four) that hold 16
+// points of two columns per thread exactly as the 256-row kernels do.  The 512-point column
+// transform is 16 x 32: n1 = a*32 + b, k1 = a' + 16*b',
+//   W_512^(n1*k1) = W_16^(a*a') * W_512^(b*a') * W_32^(b*b'),
+// a 16-point pass over a in registers, the twiddle W_512^(b*a'), an LDS exchange, and the
+// 32-point pass over b as one radix-2 stage + a 16-point pass: thread (a', half) reads all 32
+// values of its a' and forms x[b] + x[b+16] (half 0: even b') or (x[b] - x[b+16]) W_32^b (half 1:
+// odd b').  K2 sees 512 ordinary 8192-point rows per pair; K3 reads every row once.
+// ===========================================================================
+constexpr int kC512Slab = 560;   // float2 per a' slab: 32 rows of 17 + 16, so that consecutive a' sit 32 banks apart
+__device__ __forceinline__ int c512_idx(int ap, int b, int cp) { return ap * kC512Slab + b * 17 + cp; }
+constexpr int kC512Lds = (15 * kC512Slab + 31 * 17 + 16) * 8;
+constexpr int kC512LdsK3 = 512 * 16 * 8;   // the score scan needs 512 rows x 32 scores
+
+template <int KIND>
+__global__ void __launch_bounds__(512, 2)
+k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;             // pass 1: b = hi (0..31)
+    const int ap = hi & 15, half = hi >> 4;         // pass 2: a' and the parity of b'
+    const int k10 = ap + 16 * half;                 // k1 = k10 + 32 * beta
+    const int n2_0 = blockIdx.x << kColsLog;
+    const int pair = job.first_pair + blockIdx.y;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const bool validB = blkB < job.nblocks;
+    const long long N = 1ll << pl.logN;
+    const long long baseA = blkA * job.hop - job.lead;
+    const long long baseB = blkB * job.hop - job.lead;
+    const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
+                      baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
+    const long long col = (long long)n2_0 + 2 * cp;
+    const unsigned maskN = (unsigned)(N - 1);
+    const float2 w512 = pl.tw1[hi];                 // W_512^b
+    const float2 base0 = tw_big(pl, ((unsigned)col * (unsigned)k10) & maskN);
+    const float2 base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)k10) & maskN);
+    const float2 step0 = tw_big(pl, ((unsigned)col * 32u) & maskN);
+    const float2 step1 = tw_big(pl, (((unsigned)col + 1u) * 32u) & maskN);
+    float2 x0[16], x1[16];
+    if (fast) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long off = (long long)(a * 32 + hi) * kN2 + col;
+            const float2 va = load_sample2<KIND>(job.src, baseA + off), vb = load_sample2<KIND>(job.src, baseB + off);
+            x0[a] = make_float2(va.x, vb.x);
+            x1[a] = make_float2(va.y, vb.y);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * 32 + hi) * kN2 + col;
+            const float2 va = load2_padded<KIND>(job.src, baseA + n, job.src_len);
+            const float2 vb = validB ? load2_padded<KIND>(job.src, baseB + n, job.src_len) : make_float2(0.f, 0.f);
+            x0[a] = make_float2(va.x, vb.x);
+            x1[a] = make_float2(va.y, vb.y);
+        }
+    }
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    twiddle_brev<16, false>(x0, w512);   // W_512^(b*a')
+    twiddle_brev<16, false>(x1, w512);
+    // exchange, one column of the pair at a time; afterwards thread (a', half) holds
+    // w[b] = x[b] + x[b+16] or (x[b] - x[b+16]) W_32^b, b = 0..15
+    float2 y0[16], y1[16];
+#pragma unroll
+    for (int a2 = 0; a2 < 16; ++a2) lds2[c512_idx(a2, hi, cp)] = x0[brev<16>(a2)];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const float2 lo = lds2[c512_idx(ap, b, cp)], up = lds2[c512_idx(ap, b + 16, cp)];
+        y0[b] = half ? mul_w32<false>(csub(lo, up), b) : cadd(lo, up);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a2 = 0; a2 < 16; ++a2) lds2[c512_idx(a2, hi, cp)] = x1[brev<16>(a2)];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const float2 lo = lds2[c512_idx(ap, b, cp)], up = lds2[c512_idx(ap, b + 16, cp)];
+        y1[b] = half ? mul_w32<false>(csub(lo, up), b) : cadd(lo, up);
+    }
+    dif<16, false>(y0);   // beta at y[brev(beta)], b' = 2*beta + half
+    dif<16, false>(y1);
+    // W_N^(n2*k1) = W_N^(n2*k10) * (W_N^(32*n2))^beta
+    twiddle_chain<16, false, true>(y0, base0, step0);
+    twiddle_chain<16, false, true>(y1, base1, step1);
+    float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
+#pragma unroll
+    for (int bt = 0; bt < 16; ++bt) {
+        const size_t k1 = (size_t)(k10 + 32 * bt);
+        store_f4<AM_K1_STORE_NT>(out4 + k1 * (kN2 / 2), make_float4(y0[brev<16>(bt)].x, y0[brev<16>(bt)].y,
+                                                                    y1[brev<16>(bt)].x, y1[brev<16>(bt)].y));
+    }
+}
+
+__global__ void __launch_bounds__(512, 2)
+k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    const int t = threadIdx.x;
+    const int hi = t >> 4, cp = t & 15;
+    const int ap = hi & 15, half = hi >> 4;
+    const int k10 = ap + 16 * half;
+    // placement as in k3_cols_inv_r16: the 16 column tiles that share a line of the summary on one XCD
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned slot = seq >> 5, hf = (seq >> 4) & 1u, tl = seq & 15u;
+    const int n2_0 = (int)(((hf * 8u + xcd) * 16u + tl) << kColsLog);
+    const int pair = job.first_pair + (int)slot;
+    const long long blkA = 2ll * pair, blkB = blkA + 1;
+    const long long N = 1ll << pl.logN;
+    const unsigned maskN = (unsigned)(N - 1);
+    const unsigned n2 = (unsigned)n2_0 + 2u * (unsigned)cp;
+    float2 x0[16], x1[16];
+    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+#pragma unroll
+    for (int bt = 0; bt < 16; ++bt) {   // rows k1 = k10 + 32*beta
+        const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(k10 + 32 * bt) * (kN2 / 2));
+        x0[bt] = make_float2(v.x, v.y);
+        x1[bt] = make_float2(v.z, v.w);
+    }
+    const K3Edges ed = k3_edges(job, scan, blkA, blkB);
+    const float2 w512 = pl.tw1[hi];
+    {
+        const float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
+        const float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
+        const float2 step0 = tw_big(pl, (n2 * 32u) & maskN);
+        const float2 step1 = tw_big(pl, ((n2 + 1u) * 32u) & maskN);
+        twiddle_chain<16, true, false>(x0, base0, step0);
+        twiddle_chain<16, true, false>(x1, base1, step1);
+    }
+    dif<16, true>(x0);   // inverse over beta: branch value b at x[brev(b)], b = 0..15
+    dif<16, true>(x1);
+    if (half) {          // the odd-b' branch carries conj(W_32^b)
+#pragma unroll
+        for (int b = 1; b < 16; ++b) {
+            x0[brev<16>(b)] = mul_w32<true>(x0[brev<16>(b)], b);
+            x1[brev<16>(b)] = mul_w32<true>(x1[brev<16>(b)], b);
+        }
+    }
+    // exchange, one column of the pair at a time: afterwards thread b = hi (0..31) holds
+    // z[a'] = u[a'][b & 15] +- v[a'][b & 15]
+    const float sgn = hi >= 16 ? -1.0f : 1.0f;
+    const int bb = hi & 15;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[c512_idx(ap, b + 16 * half, cp)] = x0[brev<16>(b)];
+    __syncthreads();
+#pragma unroll
+    for (int a2 = 0; a2 < 16; ++a2) {
+        const float2 u = lds2[c512_idx(a2, bb, cp)], v = lds2[c512_idx(a2, bb + 16, cp)];
+        x0[a2] = make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[c512_idx(ap, b + 16 * half, cp)] = x1[brev<16>(b)];
+    __syncthreads();
+#pragma unroll
+    for (int a2 = 0; a2 < 16; ++a2) {
+        const float2 u = lds2[c512_idx(a2, bb, cp)], v = lds2[c512_idx(a2, bb + 16, cp)];
+        x1[a2] = make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
+    }
+    twiddle_nat<16, true>(x0, w512);   // conj(W_512^(b*a'))
+    twiddle_nat<16, true>(x1, w512);
+    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*32 + b
+    dif<16, true>(x1);
+    k3_finish<5>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -1241,6 +1446,8 @@ static constexpr int kR16LdsK1 = 256 * 17 * 8;   // K1: one column of the pair a
 static constexpr int kR16LdsK3 = 256 * 16 * 8;
 
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
+bool plan_is_c512(const PlanDev& pl) { return pl.logN1 == 9 && pl.logN2 == kR16LogN2 && !pl.wide; }
+bool plan_has_scan(const PlanDev& pl) { return plan_is_r16(pl) || plan_is_c512(pl); }
 // the row kernel only needs 8192-point rows; it serves any N1 (its rows are independent)
 bool plan_k2_is_r16(const PlanDev& pl) { return pl.logN2 == kR16LogN2 && pl.logN1 >= 3; }
 
@@ -1261,6 +1468,9 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k1_cols_fwd_w16<0>, kR16LdsK1)
     AM_SET_LDS(k1_cols_fwd_w16<1>, kR16LdsK1)
     AM_SET_LDS(k3_cols_inv_w16, kR16LdsK3)
+    AM_SET_LDS(k1_cols_fwd_c512<0>, kC512Lds)
+    AM_SET_LDS(k1_cols_fwd_c512<1>, kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512, kC512Lds)
     AM_SET_LDS(k3_cols_inv_r16<false>, kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_r16<true>, kR16LdsK3)
     AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
@@ -1274,7 +1484,10 @@ hipError_t fft_kernels_init() {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     const bool pcm = job.src_kind == 1;
-    if (plan_is_r16(pl) && pl.wide) {
+    if (plan_is_c512(pl)) {
+        if (pcm) hipLaunchKernelGGL(k1_cols_fwd_c512<1>, grid, dim3(512), kC512Lds, st, job, work, pl);
+        else hipLaunchKernelGGL(k1_cols_fwd_c512<0>, grid, dim3(512), kC512Lds, st, job, work, pl);
+    } else if (plan_is_r16(pl) && pl.wide) {
         if (pcm) hipLaunchKernelGGL(k1_cols_fwd_w16<1>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
         else hipLaunchKernelGGL(k1_cols_fwd_w16<0>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
     } else if (plan_is_r16(pl)) {
@@ -1329,11 +1542,14 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
     return hipGetLastError();
 }
 
-// scan.stats32 != nullptr only for the r16 plan with a 1024-aligned hop
+// scan.stats32 != nullptr only for the plans with a fused scan (plan_has_scan) and a 1024-aligned hop
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
-    if (plan_is_r16(pl) && pl.wide) {
+    if (plan_is_c512(pl)) {
+        hipLaunchKernelGGL(k3_cols_inv_c512, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+                           pl, out_scale, scan);
+    } else if (plan_is_r16(pl) && pl.wide) {
         hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * 2u * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                            pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
