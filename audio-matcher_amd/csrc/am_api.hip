@@ -76,8 +76,9 @@ struct Opts {
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
-// needles longer than this run on N = 2^22 (measured crossover, tools/needle_sweep.py)
-static const long long kWideFromSamples = 7 * (1ll << 16);
+// needles longer than this run on N = 2^22 (measured crossover between 4 and 7 s of 44.1 kHz
+// audio, tools/needle_sweep.py, profiles/r02/needle_sweep.txt)
+static const long long kWideFromSamples = 300000;
 
 // ---------------------------------------------------------------------------
 struct DevBuf {
@@ -242,14 +243,7 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     if (logN1 < kColsLog) logN1 = kColsLog;
     if (logN1 > 9) logN1 = 9;
     int logN2 = logN - logN1;
-    // N = 2^22 runs on the register kernels as 256 columns x two 8192-point row halves
-    // (AM_PLAN22_W16 = 1 selects the older form of this plan: rows split by one radix-2 stage
-    // into halves, 256-thread column kernels that handle two tiles; kept for A/B measurements)
-#ifndef AM_PLAN22_W16
-#define AM_PLAN22_W16 0
-#endif
-    const int wide = (logN == 22 && AM_PLAN22_W16) ? 1 : 0;
-    if (wide) { logN1 = 8; logN2 = 13; }
+    // N = 2^21 -> 256 x 8192 and N = 2^22 -> 512 x 8192: the register kernels
     const int logLo = (logN + 1) / 2;
     const size_t n1h = (size_t)1 << (logN1 - 1), n2h = (size_t)1 << (logN2 - 1);
     const size_t nlo = (size_t)1 << logLo, nhi = (size_t)1 << (logN - logLo);
@@ -260,7 +254,7 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     fill_twiddles(host, n1h + n2h + nlo, nhi, (double)((size_t)1 << logN), (double)nlo);
     AM_HIP(hipMalloc((void**)&p.tables, host.size() * sizeof(float2)));
     AM_HIP(copy_on_stream(c, p.tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
-    p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo; p.dev.wide = wide;
+    p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo;
     p.dev.tw1 = p.tables;
     p.dev.tw2 = p.tables + n1h;
     p.dev.twlo = p.tables + n1h + n2h;
@@ -389,7 +383,7 @@ static int plan_geometry(size_t s, long long out_count, const Opts& o, Geometry*
     g->npairs = (g->nblocks + 1) / 2;
     return AM_OK;
 }
-static bool use_half(const Opts& o, const PlanDev& pl) { return o.half && plan_is_r16(pl) && !pl.wide; }
+static bool use_half(const Opts& o, const PlanDev& pl) { return o.half && plan_is_r16(pl); }
 
 static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
@@ -422,12 +416,12 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
-        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
+        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
             DevBuf& b32 = scan_req->set ? c->stats32_b : c->stats32;
             DevBuf& bwf = scan_req->set ? c->wflags_b : c->wflags;
             if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-            if ((rc = bwf.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;
+            if ((rc = bwf.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
             scan.stats32 = (float2*)b32.p;
             scan.wflags = (unsigned char*)bwf.p;
             scan.theta = scan_req->theta;
@@ -435,7 +429,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
             scan.seg_d = scan_req->seg_d;
             scan.inv_c = scan.seg_c > 0 ? 1.0 / (double)scan.seg_c : 0.0;
             scan_req->fused = true;
-            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
+            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         }
     }
     // half-precision storage of the work matrix: K2 normalises by the needle
@@ -876,7 +870,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     const bool fused = plan_has_scan(pl->dev) && (hop % kTile) == 0;
     if (fused) {
         if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-        if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 + pl->dev.wide - kColsLog)))) return rc;
+        if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
     }
     Job job{};
     job.src = d_hay; job.src_len = (long long)len; job.lead = 0; job.src_kind = src_kind;
@@ -899,12 +893,12 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         scan.seg_c = (long long)p->chunk;
         scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
         scan.fused = fused;
-        scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
+        scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         ScanCfg cfg{};
         if (fused) {
             cfg.stats32 = (float2*)c->stats32.p; cfg.wflags = (unsigned char*)c->wflags.p; cfg.theta = scan.theta;
             cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
-            scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2 + pl->dev.wide, 1.0 / (double)hop};
+            scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         }
         const float factor = scale_factor(h, p->scale, 1);
         const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;

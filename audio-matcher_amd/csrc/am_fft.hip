@@ -24,8 +24,8 @@
 //                    scores for the peak pick.
 //
 // Three families of kernels exist:
-//   *_w16 : K1/K3 for N = 2^22 = 256 x (2 x 8192) (longer needles): one radix-2
-//           stage splits each 16384-point row into two 8192-point rows for K2.
+//   *_c512: K1/K3 for N = 2^22 = 512 x 8192 (needles above ~7 s): 512-thread column
+//           kernels, 512-point column transform as 16 x 32.
 //   *_r16 : the production shape N1 = 256, N2 = 8192 (N = 2^21).  Radix-16/32
 //           butterflies held in VGPRs, LDS used only for the exchanges between
 //           passes (conflict-free 16-byte accesses, XOR-swizzled rows), 16-byte
@@ -376,53 +376,6 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
         const size_t k1 = (size_t)(hi + 16 * bp);
         store_f4<AM_K1_STORE_NT>(out4 + k1 * (kN2 / 2), make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
                                                                     x1[brev<16>(bp)].x, x1[brev<16>(bp)].y));
-    }
-}
-
-// K1 for N = 2^22 = 256 x 16384: the 16384-point rows are split by one radix-2
-// stage into two 8192-point rows (even / odd frequencies) that K2 handles as
-// independent rows.  One workgroup transforms the two column tiles m and m + 8192,
-// forms s = A + B and d = (A - B) * W_16384^m and stores them as work rows
-// 2*k1 and 2*k1 + 1.
-template <int KIND>
-__global__ void __launch_bounds__(256, 2)
-k1_cols_fwd_w16(Job job, float2* __restrict__ work, PlanDev pl) {
-    extern __shared__ float4 lds4[];
-    const int t = threadIdx.x;
-    const int hi = t >> 4, cp = t & 15;
-    const int m_0 = blockIdx.x << kColsLog;
-    const int pair = job.first_pair + blockIdx.y;
-    const long long blkA = 2ll * pair, blkB = blkA + 1;
-    const bool validB = blkB < job.nblocks;
-    const long long N = 1ll << pl.logN;
-    const long long baseA = blkA * job.hop - job.lead;
-    const long long baseB = blkB * job.hop - job.lead;
-    const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
-                      baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
-    const long long m = (long long)m_0 + 2 * cp;
-    const unsigned maskN = (unsigned)(N - 1);
-    // W_16384^m = W_N^(256 m)
-    const float2 wd0 = tw_big(pl, ((unsigned)m * 256u) & maskN);
-    const float2 wd1 = tw_big(pl, (((unsigned)m + 1u) * 256u) & maskN);
-    float2 a0[16], a1[16], x0[16], x1[16];
-    float2* lds2 = reinterpret_cast<float2*>(lds4);
-    // both tiles' samples are requested before the first transform starts: the second tile's
-    // loads are in flight while the first is computed
-    const K1Twiddles wa = k1_twiddles(pl, m, hi), wx = k1_twiddles(pl, m + kN2, hi);
-    k1_load<KIND>(job, m, 2 * kN2, hi, baseA, baseB, validB, fast, a0, a1);
-    k1_load<KIND>(job, m + kN2, 2 * kN2, hi, baseA, baseB, validB, fast, x0, x1);
-    k1_transform(wa, lds2, hi, cp, a0, a1);
-    __syncthreads();   // the LDS tile is reused
-    k1_transform(wx, lds2, hi, cp, x0, x1);
-    float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + m_0) + cp;
-#pragma unroll
-    for (int bp = 0; bp < 16; ++bp) {
-        const int i = brev<16>(bp);
-        const float2 s0 = cadd(a0[i], x0[i]), s1 = cadd(a1[i], x1[i]);
-        const float2 d0 = cmul(csub(a0[i], x0[i]), wd0), d1 = cmul(csub(a1[i], x1[i]), wd1);
-        const size_t k1 = (size_t)(hi + 16 * bp);
-        out4[(2 * k1) * (kN2 / 2)] = make_float4(s0.x, s0.y, s1.x, s1.y);
-        out4[(2 * k1 + 1) * (kN2 / 2)] = make_float4(d0.x, d0.y, d1.x, d1.y);
     }
 }
 
@@ -1010,46 +963,8 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
-// K3 for N = 2^22 (see k1_cols_fwd_w16): rows 2*k1 / 2*k1+1 of the work matrix hold
-// the inverse 8192-point transforms e / o of the even / odd row frequencies;
-// y[m] = e + conj(W_16384^m) o and y[m + 8192] = e - conj(W_16384^m) o are the two
-// column tiles m and m + 8192.  Each workgroup produces ONE of the two tiles (so it
-// keeps the register footprint and occupancy of the 2^21 kernel) and therefore
-// reads both row halves; the two workgroups of a tile pair are adjacent on one XCD,
-// so the second read of a line is served by that L2.
-__global__ void __launch_bounds__(256, 3)
-k3_cols_inv_w16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
-    extern __shared__ float4 lds4[];
-    const int t = threadIdx.x;
-    const int hi = t >> 4, cp = t & 15;
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
-    const unsigned h = seq & 1u, rest = seq >> 1;
-    const unsigned slot = rest >> 5, half = (rest >> 4) & 1u, tl = rest & 15u;
-    const int m_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
-    const int pair = job.first_pair + (int)slot;
-    const long long blkA = 2ll * pair, blkB = blkA + 1;
-    const long long N = 1ll << pl.logN;
-    const unsigned maskN = (unsigned)(N - 1);
-    const unsigned m = (unsigned)m_0 + 2u * (unsigned)cp;
-    const float sgn = h ? -1.0f : 1.0f;
-    float2 wd0 = tw_big(pl, (m * 256u) & maskN);
-    float2 wd1 = tw_big(pl, ((m + 1u) * 256u) & maskN);
-    wd0 = make_float2(sgn * wd0.x, -sgn * wd0.y);   // +-conj(W_16384^m)
-    wd1 = make_float2(sgn * wd1.x, -sgn * wd1.y);
-    float2 x0[16], x1[16];
-    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + m_0) + cp;
-#pragma unroll
-    for (int bp = 0; bp < 16; ++bp) {
-        const size_t k1 = (size_t)(hi + 16 * bp);
-        const float4 ve = in4[(2 * k1) * (kN2 / 2)], vo = in4[(2 * k1 + 1) * (kN2 / 2)];
-        x0[bp] = cadd(make_float2(ve.x, ve.y), cmul(make_float2(vo.x, vo.y), wd0));
-        x1[bp] = cadd(make_float2(ve.z, ve.w), cmul(make_float2(vo.z, vo.w), wd1));
-    }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), m_0 + (int)h * kN2, 2 * kN2, t, blkA, blkB, out_scale, x0, x1);
-}
-
 // ===========================================================================
-// N = 2^22 = 512 x 8192 without the row split: column kernels with 512 threads (two waves
+// N = 2^22 = 512 x 8192: column kernels with 512 threads (two waves
 // per SIMD; two workgroups = 16 waves per CU, like the 256-thread kernels at four) that hold 16
 // points of two columns per thread exactly as the 256-row kernels do.  The 512-point column
 // transform is 16 x 32: n1 = a*32 + b, k1 = a' + 16*b',
@@ -1446,7 +1361,7 @@ static constexpr int kR16LdsK1 = 256 * 17 * 8;   // K1: one column of the pair a
 static constexpr int kR16LdsK3 = 256 * 16 * 8;
 
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
-bool plan_is_c512(const PlanDev& pl) { return pl.logN1 == 9 && pl.logN2 == kR16LogN2 && !pl.wide; }
+bool plan_is_c512(const PlanDev& pl) { return pl.logN1 == 9 && pl.logN2 == kR16LogN2; }
 bool plan_has_scan(const PlanDev& pl) { return plan_is_r16(pl) || plan_is_c512(pl); }
 // the row kernel only needs 8192-point rows; it serves any N1 (its rows are independent)
 bool plan_k2_is_r16(const PlanDev& pl) { return pl.logN2 == kR16LogN2 && pl.logN1 >= 3; }
@@ -1465,9 +1380,6 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k1_cols_fwd_r16<1, false>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<0, true>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<1, true>), kR16LdsK1)
-    AM_SET_LDS(k1_cols_fwd_w16<0>, kR16LdsK1)
-    AM_SET_LDS(k1_cols_fwd_w16<1>, kR16LdsK1)
-    AM_SET_LDS(k3_cols_inv_w16, kR16LdsK3)
     AM_SET_LDS(k1_cols_fwd_c512<0>, kC512Lds)
     AM_SET_LDS(k1_cols_fwd_c512<1>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_c512, kC512Lds)
@@ -1487,9 +1399,6 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
     if (plan_is_c512(pl)) {
         if (pcm) hipLaunchKernelGGL(k1_cols_fwd_c512<1>, grid, dim3(512), kC512Lds, st, job, work, pl);
         else hipLaunchKernelGGL(k1_cols_fwd_c512<0>, grid, dim3(512), kC512Lds, st, job, work, pl);
-    } else if (plan_is_r16(pl) && pl.wide) {
-        if (pcm) hipLaunchKernelGGL(k1_cols_fwd_w16<1>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
-        else hipLaunchKernelGGL(k1_cols_fwd_w16<0>, grid, dim3(256), kR16LdsK1, st, job, work, pl);
     } else if (plan_is_r16(pl)) {
         if (half) {
             if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
@@ -1510,9 +1419,9 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
                      bool half, float hscale) {
     const dim3 grid(1u << pl.logN1, npairs);
     if (plan_k2_is_r16(pl)) {
-        if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, hc,
+        if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
-        else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, hc,
+        else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                 dst, pl, (unsigned)npairs, 1.0f);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
@@ -1525,7 +1434,7 @@ bool plan_k2_has_group(const PlanDev& pl) { return plan_k2_is_r16(pl); }
 
 hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const K2Group& grp, const PlanDev& pl) {
     if (!plan_k2_has_group(pl) || grp.n < 1 || grp.n > kMaxNeedleGroup) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k2_rows_r16_group, dim3((unsigned)npairs << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, grp, pl,
+    hipLaunchKernelGGL(k2_rows_r16_group, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, grp, pl,
                        (unsigned)npairs);
     return hipGetLastError();
 }
@@ -1533,7 +1442,7 @@ hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl) {
     const dim3 grid(1u << pl.logN1, 1);
     if (plan_k2_is_r16(pl)) {
-        hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << (pl.logN1 + pl.wide)), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
+        hipLaunchKernelGGL((k2_rows_r16<true, false>), dim3(1u << pl.logN1), dim3(256), kR16Lds, st, work, (const float2*)nullptr,
                            hc_out, pl, 1u, 1.0f);
     } else {
         const size_t lds = sizeof(float2) << pl.logN2;
@@ -1548,9 +1457,6 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_c512(pl)) {
         hipLaunchKernelGGL(k3_cols_inv_c512, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
-                           pl, out_scale, scan);
-    } else if (plan_is_r16(pl) && pl.wide) {
-        hipLaunchKernelGGL(k3_cols_inv_w16, dim3((unsigned)npairs * 2u * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                            pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,

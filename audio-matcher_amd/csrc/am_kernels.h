@@ -29,7 +29,6 @@ struct Job {
 // Factorisation N = N1 * N2 of the complex transform and its twiddle tables.
 struct PlanDev {
     int logN, logN1, logN2, logLo;
-    int wide;             // 1: N = 2^22 as 256 x (2 x 8192): rows are halves of 16384-point rows
     const float2* tw1;    // W_N1^k, k < N1/2 (forward sign)
     const float2* tw2;    // W_N2^k, k < N2/2
     const float2* twlo;   // W_N^m,            m < 2^logLo

@@ -382,7 +382,7 @@ def main():
     # ---- roofline of the dominant kernel (algorithmic bytes) ----
     log_n = am.get_option("log_n") or 0
     if not log_n:
-        log_n = 21 if s <= 7 * 65536 else 22   # the library's plan for this needle (am_api.hip pick_log_n)
+        log_n = 21 if s <= 300000 else 22   # the library's plan for this needle (am_api.hip pick_log_n)
     n_fft = 2 ** log_n
     hop = n_fft - s + 1
     if hop >= 8192:
