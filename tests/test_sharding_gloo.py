@@ -10,6 +10,14 @@ import textwrap
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
+
+def free_port() -> str:
+    """A port nobody listens on right now (two test runs on one machine must not collide)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
 WORKER = textwrap.dedent("""
     import json, os, sys
     sys.path.insert(0, os.path.join(%(root)r, "audio-matcher_amd", "python"))
@@ -40,7 +48,7 @@ WORKER = textwrap.dedent("""
 def test_two_rank_shard_and_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
@@ -82,7 +90,7 @@ def test_bench_control_plane_two_ranks(tmp_path):
     values, k mod N shard) with world_size 2 on the CPU -- the data path has no collective."""
     script = tmp_path / "bench_worker.py"
     script.write_text(BENCH_WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=300) for p in procs]
