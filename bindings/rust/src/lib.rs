@@ -193,3 +193,55 @@ impl Drop for HipConvolve {
         unsafe { am_needle_destroy(self.h) }
     }
 }
+
+/// The file loop of `matcher::run` (matcher/mod.rs:42-87) over every GPU of the node: the needle
+/// replicated per device, haystack `k` matched on device `k mod n` (no exchange step), one submit
+/// thread per device inside the library, every result in the slot of its haystack.
+pub struct HipConvolvePool {
+    p: *mut AmPool,
+}
+unsafe impl Send for HipConvolvePool {}
+
+impl HipConvolvePool {
+    /// `devices = None`: every visible device
+    pub fn new(sample_data: &[f32], devices: Option<&[c_int]>) -> Result<Self, Box<dyn std::error::Error>> {
+        let mut p = std::ptr::null_mut();
+        let (dp, dn) = match devices {
+            Some(d) => (d.as_ptr(), d.len()),
+            None => (std::ptr::null(), 0),
+        };
+        let rc = unsafe { am_pool_create(sample_data.as_ptr(), sample_data.len(), dp, dn, &mut p) };
+        if rc != AM_OK {
+            return Err(am_err(rc));
+        }
+        Ok(Self { p })
+    }
+
+    /// `calc_chunks` for every haystack of the batch; result `k` belongs to `haystacks[k]`
+    pub fn calc_chunks(&mut self, p: &AmMatchParams, haystacks: &[&[f32]]) -> Result<Vec<Vec<AmPeak>>, Box<dyn std::error::Error>> {
+        let ptrs: Vec<*const f32> = haystacks.iter().map(|h| h.as_ptr()).collect();
+        let lens: Vec<usize> = haystacks.iter().map(|h| h.len()).collect();
+        let mut cap = 64usize;
+        loop {
+            let mut buf = vec![AmPeak::default(); cap * haystacks.len().max(1)];
+            let mut n = vec![0usize; haystacks.len()];
+            let rc = unsafe {
+                am_pool_match_batch(self.p, ptrs.as_ptr(), lens.as_ptr(), haystacks.len(), p, buf.as_mut_ptr(), cap, n.as_mut_ptr())
+            };
+            if rc == AM_ERR_CAPACITY {
+                cap = n.iter().copied().max().unwrap_or(cap).max(cap + 1);
+                continue;
+            }
+            if rc != AM_OK {
+                return Err(am_err(rc));
+            }
+            return Ok((0..haystacks.len()).map(|k| buf[k * cap..k * cap + n[k]].to_vec()).collect());
+        }
+    }
+}
+
+impl Drop for HipConvolvePool {
+    fn drop(&mut self) {
+        unsafe { am_pool_destroy(self.p) }
+    }
+}
