@@ -166,7 +166,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 #define AM_K3_LOAD_NT 1   // K3's once-read column loads: 0.180 -> 0.156 ms per 1 h haystack (profiles/r02/nt_ab.txt)
 #endif
 #ifndef AM_K1_LOAD_NT
-#define AM_K1_LOAD_NT 0
+#define AM_K1_LOAD_NT 1   // K1's sample loads: 0.269 -> 0.261 ms with the 512-row kernel (profiles/r02/nt_ab_c512.txt)
 #endif
 template <int AUX = 0>
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -977,7 +977,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
 constexpr int kC512Slab = 560;   // float2 per a' slab: 32 rows of 17 + 16, so that consecutive a' sit 32 banks apart
 __device__ __forceinline__ int c512_idx(int ap, int b, int cp) { return ap * kC512Slab + b * 17 + cp; }
 constexpr int kC512Lds = (15 * kC512Slab + 31 * 17 + 16) * 8;
-constexpr int kC512LdsK3 = 512 * 16 * 8;   // the score scan needs 512 rows x 32 scores
+static_assert(kC512Lds >= 512 * 16 * 8, "K3's score scan needs 512 rows x 32 scores");
 
 template <int KIND>
 __global__ void __launch_bounds__(512, 2)
