@@ -489,3 +489,35 @@ def test_default_distance_with_thousands_of_qualifying_maxima(gpu, oracle):
         assert ref[0][0] < n - 100                                          # not the last crest
         got = gpu.find_peaks(y, 0.13, n)
         assert [(g.start, g.end, g.height, g.prominence) for g in got] == [tuple(r) for r in ref]
+
+
+def test_512_row_plan_on_pcm16_and_several_needles(gpu, oracle):
+    """The N = 2^22 plan (512 x 8192, 512-thread column kernels; needles above 300 000 samples) on
+    the two other ingest paths: interleaved i16 stereo frames (down-mix fused into K1) and several
+    needles against one haystack (grouped K2 over 512 rows per pair)."""
+    sr = 48000
+    needle_lr, hay_lr = pcm_case(oracle, sr, 7.0, 95.0, [11.0, 70.5], 61)        # 336 000 frames per needle
+    needle = oracle.pcm_s16_stereo_to_mono(needle_lr)
+    hay = oracle.pcm_s16_stereo_to_mono(hay_lr)
+    cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=7.0, distance_s=30.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+    assert [e[0] for e in exp] == [11 * sr, int(70.5 * sr)]
+    algo = gpu.HipConvolve.from_pcm16(needle_lr)
+    for _ in range(2):
+        assert_same(algo.match_pcm16(hay_lr, p), exp)
+    # three needles of that length, one haystack: equal to separate calls
+    others = [oracle.synth_uniform(61, 200 + k, 0, needle.size) for k in range(2)]
+    hay2 = hay.copy()
+    for k, n2 in enumerate(others):
+        off = int((25.0 + 30.0 * k) * sr)
+        hay2[off:off + n2.size] += n2
+    algos = [gpu.HipConvolve(needle)] + [gpu.HipConvolve(n2) for n2 in others]
+    buf = gpu.DeviceBuffer.from_numpy(0, hay2)
+    res = gpu.match_multi_device(algos, buf.ptr, hay2.size, p)
+    singles = [a.match_device(buf.ptr, hay2.size, p) for a in algos]
+    assert [[q.start for q in r] for r in res] == [[11 * sr, int(70.5 * sr)], [25 * sr], [55 * sr]]
+    for got, one in zip(res, singles):
+        assert [(g.start, g.end) for g in got] == [(g.start, g.end) for g in one]
+        for g, o in zip(got, one):
+            assert abs(g.height - o.height) < 2e-6 and abs(g.prominence - o.prominence) < 2e-6
