@@ -303,7 +303,10 @@ __device__ bool prominence(const float* __restrict__ g, const float2* __restrict
 //      wave-cooperative walk through global memory (prominence()).
 // All three use the walk's own arithmetic (the same minima over the same scores, the same
 // comparisons), so the outcome is bit-identical to walking every candidate.
-constexpr int kHalo = 256;
+#ifndef AM_PEAK_HALO
+#define AM_PEAK_HALO 256
+#endif
+constexpr int kHalo = AM_PEAK_HALO;
 constexpr int kNear = 32;
 constexpr int kWin = kTile + 2 * kHalo;
 constexpr int kWinRuns = kWin / 32 + 1;   // 32-score runs (aligned to absolute multiples of 32) a window can touch
