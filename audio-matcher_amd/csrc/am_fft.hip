@@ -978,6 +978,14 @@ constexpr int kC512Slab = 560;   // float2 per a' slab: 32 rows of 17 + 16, so t
 __device__ __forceinline__ int c512_idx(int ap, int b, int cp) { return ap * kC512Slab + b * 17 + cp; }
 constexpr int kC512Lds = (15 * kC512Slab + 31 * 17 + 16) * 8;
 static_assert(kC512Lds >= 512 * 16 * 8, "K3's score scan needs 512 rows x 32 scores");
+// K3's exchange runs the other way round (written per a' slab by lanes that differ in a', read by
+// lanes that differ in b): rows of 16 put consecutive b 32 banks apart for the reads, and a slab of
+// 32 * 16 + 16 does the same for consecutive a' in the writes.  (With K1's row stride of 17 a
+// quarter of K3's LDS cycles were bank conflicts: the two rows of a 32-lane group overlapped in
+// two banks.)
+constexpr int kC512Slab3 = 32 * 16 + 16;
+__device__ __forceinline__ int c512_idx3(int ap, int b, int cp) { return ap * kC512Slab3 + b * 16 + cp; }
+static_assert((15 * kC512Slab3 + 31 * 16 + 16) * 8 <= kC512Lds, "K3's exchange fits the kernel's LDS");
 
 template <int KIND>
 __global__ void __launch_bounds__(512, 2)
@@ -1110,20 +1118,20 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const float sgn = hi >= 16 ? -1.0f : 1.0f;
     const int bb = hi & 15;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) lds2[c512_idx(ap, b + 16 * half, cp)] = x0[brev<16>(b)];
+    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = x0[brev<16>(b)];
     __syncthreads();
 #pragma unroll
     for (int a2 = 0; a2 < 16; ++a2) {
-        const float2 u = lds2[c512_idx(a2, bb, cp)], v = lds2[c512_idx(a2, bb + 16, cp)];
+        const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
         x0[a2] = make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
     }
     __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 16; ++b) lds2[c512_idx(ap, b + 16 * half, cp)] = x1[brev<16>(b)];
+    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = x1[brev<16>(b)];
     __syncthreads();
 #pragma unroll
     for (int a2 = 0; a2 < 16; ++a2) {
-        const float2 u = lds2[c512_idx(a2, bb, cp)], v = lds2[c512_idx(a2, bb + 16, cp)];
+        const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
         x1[a2] = make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
     }
     twiddle_nat<16, true>(x0, w512);   // conj(W_512^(b*a'))
