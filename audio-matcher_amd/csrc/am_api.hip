@@ -311,9 +311,8 @@ static int pick_log_n(size_t s, long long out_count, const Opts& o, int* logN_ou
     // faster per point than the generic ones, so every problem that is not small runs on
     // them; short needles simply get a longer hop.
     if (span > (1ll << 19)) {
-        // measured crossover (tools/needle_sweep.py); the half-precision
-        // work matrix exists on the 2^21 plan only: keep it there up to 2^19 samples
-        if ((long long)s <= (o.half ? (1ll << 19) : kWideFromSamples)) { *logN_out = 21; return AM_OK; }
+        // measured crossover (tools/needle_sweep.py)
+        if ((long long)s <= kWideFromSamples) { *logN_out = 21; return AM_OK; }
         if ((long long)s <= (1ll << 22) - (1ll << 20)) { *logN_out = 22; return AM_OK; }
     }
     int pref = min_log;
@@ -383,7 +382,28 @@ static int plan_geometry(size_t s, long long out_count, const Opts& o, Geometry*
     g->npairs = (g->nblocks + 1) / 2;
     return AM_OK;
 }
-static bool use_half(const Opts& o, const PlanDev& pl) { return o.half && plan_is_r16(pl); }
+// Half-precision levels (option "half_pipeline"): 1 = the work matrix travels through HBM as f16,
+// butterflies in f32; 2 = K2's butterflies in packed f16 as well.  The scales keep every stored
+// or f16-computed value inside f16's range: level 1 normalises K2's product by the needle energy
+// (times a fixed gain); level 2 scales the row by 2^-7 on the way into K2 (a full-scale tone then
+// peaks at 2^15 in the forward spectrum) and the needle spectrum to an rms of 1/8 per bin.  K3
+// divides the scales out in f32.
+struct HalfScale {
+    int level;
+    float pre, hscale;
+    float k3(float factor) const { return level ? factor / (hscale * pre) : factor; }
+};
+static HalfScale half_scale(const am_needle* h, const Opts& o, const PlanDev& pl) {
+    HalfScale s{0, 1.0f, 1.0f};
+    if (!o.half || !(plan_is_r16(pl) || plan_is_c512(pl))) return s;
+    s.level = o.half >= 2 ? 2 : 1;
+    if (s.level == 1) s.hscale = kHalfGain * h->inv_autocorr;
+    else {
+        s.pre = 1.0f / 128.0f;
+        s.hscale = (float)((double)(1ull << pl.logN) * std::sqrt((double)h->inv_autocorr) / 8.0);
+    }
+    return s;
+}
 
 static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
@@ -434,9 +454,9 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     }
     // half-precision storage of the work matrix: K2 normalises by the needle
     // energy (times a fixed gain) so that stored values sit mid-range in f16
-    const bool half = use_half(o, pl->dev);
-    const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
-    const float k3scale = half ? factor / hscale : factor;
+    const HalfScale hs = half_scale(h, o, pl->dev);
+    const bool half = hs.level != 0;
+    const float k3scale = hs.k3(factor);
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
@@ -450,7 +470,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         const int np = (int)std::min(ppg, pair_hi - first);
         job.first_pair = (int)first;
         { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, half, hscale)); }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre)); }
         if (!waited && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
         waited = true;
         { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
@@ -855,7 +875,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     for (size_t k = 0; k < nn; ++k)
         if ((rc = needle_spectrum(needles[k], pl, &hcs[k]))) return rc;   // may use c->work: before it is filled
     if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
-    const bool half = use_half(o, pl->dev);
+    const bool half = o.half && (plan_is_r16(pl->dev) || plan_is_c512(pl->dev));
     // needles are taken in groups that share the forward row transforms of K2
     const size_t group = (!half && plan_k2_has_group(pl->dev))
         ? (size_t)std::min<long long>(std::max<long long>(1, o.needle_group), kMaxNeedleGroup) : 1;
@@ -901,10 +921,10 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
             scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
         }
         const float factor = scale_factor(h, p->scale, 1);
-        const float hscale = half ? kHalfGain * h->inv_autocorr : 1.0f;
-        if (group == 1) { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, half, hscale)); }
+        const HalfScale hs = half_scale(h, o, pl->dev);
+        if (group == 1) { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, hs.level, hs.hscale, hs.pre)); }
         { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, inv_rows, pl->dev,
-                                                  half ? factor / hscale : factor, cfg, half)); }
+                                                  hs.k3(factor), cfg, half)); }
         if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
                               (long long)p->min_distance, &scan, (int)(k * nsegs), arena))) return rc;
     }
@@ -1607,7 +1627,7 @@ int am_set_option(const char* key, long long value) {
         if (value != 0 && (value < kLogNMin || value > kLogNMax)) return fail(AM_ERR_INVALID_ARG, "log_n out of range");
         g_opt_log_n = value; return AM_OK;
     }
-    if (!strcmp(key, "half_pipeline")) { g_opt_half = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "half_pipeline")) { g_opt_half = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
@@ -1640,7 +1660,7 @@ int am_needle_set_option(am_needle* h, const char* key, long long value) {
         if (value > 0 && (value < kLogNMin || value > kLogNMax)) return fail(AM_ERR_INVALID_ARG, "log_n out of range");
         h->opt_log_n = value < 0 ? -1 : value; return AM_OK;
     }
-    if (!strcmp(key, "half_pipeline")) { h->opt_half = value < 0 ? -1 : (value ? 1 : 0); return AM_OK; }
+    if (!strcmp(key, "half_pipeline")) { h->opt_half = value < 0 ? -1 : (value >= 2 ? 2 : (value ? 1 : 0)); return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown per-handle option (log_n, half_pipeline)");
 }
 int am_needle_get_option(const am_needle* h, const char* key, long long* value) {

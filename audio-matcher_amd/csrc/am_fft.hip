@@ -93,12 +93,35 @@ __device__ __forceinline__ float2 mul_w32(float2 d, int idx) {
     return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
 }
 
-template <int R, bool INV>
-__device__ __forceinline__ void dif(float2* x) {
+// Half-precision complex arithmetic (option half_pipeline = 2: K2's butterflies in packed f16).
+// One complex point is one 32-bit register; a complex add is one v_pk_add_f16, a complex
+// multiply two packed instructions (the swap and the signs ride on op_sel / neg modifiers).
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 cadd(h2 a, h2 b) { return a + b; }
+__device__ __forceinline__ h2 csub(h2 a, h2 b) { return a - b; }
+__device__ __forceinline__ h2 cmul(h2 a, h2 b) {
+    const h2 t = a * b.xx;
+    return __builtin_elementwise_fma(a.yx, (h2){-b.y, b.y}, t);
+}
+__device__ __forceinline__ h2 mul_neg_i(h2 a) { return (h2){a.y, -a.x}; }
+__device__ __forceinline__ h2 mul_pos_i(h2 a) { return (h2){-a.y, a.x}; }
+__device__ __forceinline__ h2 to_h2(float2 v) { return (h2){(_Float16)v.x, (_Float16)v.y}; }
+template <bool INV>
+__device__ __forceinline__ h2 mul_w32(h2 d, int idx) {
+    if (idx == 0) return d;
+    if (idx == 8) return INV ? mul_pos_i(d) : mul_neg_i(d);
+    const _Float16 c = (_Float16)kCos32[idx], s = (_Float16)kSin32[idx];
+    const h2 t = d * (h2){c, c};
+    if (INV) return __builtin_elementwise_fma(d.yx, (h2){-s, s}, t);
+    return __builtin_elementwise_fma(d.yx, (h2){s, -s}, t);
+}
+
+template <int R, bool INV, typename T>
+__device__ __forceinline__ void dif(T* x) {
     if constexpr (R >= 2) {
 #pragma unroll
         for (int i = 0; i < R / 2; ++i) {
-            const float2 a = x[i], b = x[i + R / 2];
+            const T a = x[i], b = x[i + R / 2];
             x[i] = cadd(a, b);
             x[i + R / 2] = mul_w32<INV>(csub(a, b), i * (32 / R));
         }
@@ -124,6 +147,21 @@ __device__ __forceinline__ void twiddle_apply(float2* x, float2 w) {
         x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], v);
     }
 }
+// the same on half-precision points: the powers are formed in f32 (a chain of f16 products would
+// carry several roundings into every twiddle) and rounded once
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_apply(h2* x, float2 w) {
+    float2 pw[R / 2 + 1];
+    if (CONJ) w.y = -w.y;
+    pw[1] = w;
+    x[BREV ? brev<R>(1) : 1] = cmul(x[BREV ? brev<R>(1) : 1], to_h2(w));
+#pragma unroll
+    for (int e = 2; e < R; ++e) {
+        const float2 v = cmul(pw[(e + 1) / 2], pw[e / 2]);
+        if (e <= R / 2) pw[e] = v;
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], to_h2(v));
+    }
+}
 // x[idx(e)] *= base * step^e (or the conjugates), e = 0..R-1, as one running
 // product c[e] = c[e-1] * step: R-1 products instead of a separate base pass.
 template <int R, bool CONJ, bool BREV>
@@ -137,10 +175,10 @@ __device__ __forceinline__ void twiddle_chain(float2* x, float2 base, float2 ste
         x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], c);
     }
 }
-template <int R, bool CONJ>
-__device__ __forceinline__ void twiddle_brev(float2* x, float2 w) { twiddle_apply<R, CONJ, true>(x, w); }
-template <int R, bool CONJ>
-__device__ __forceinline__ void twiddle_nat(float2* x, float2 w) { twiddle_apply<R, CONJ, false>(x, w); }
+template <int R, bool CONJ, typename T>
+__device__ __forceinline__ void twiddle_brev(T* x, float2 w) { twiddle_apply<R, CONJ, true>(x, w); }
+template <int R, bool CONJ, typename T>
+__device__ __forceinline__ void twiddle_nat(T* x, float2 w) { twiddle_apply<R, CONJ, false>(x, w); }
 
 // 16-byte buffer accesses: one VGPR of address for a whole unrolled sequence
 // (per-access offsets live in SGPRs / immediates).
@@ -610,6 +648,128 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     k2_inverse<HALF>(k, q, lds4, rdst);
 }
 
+// K2 with half-precision butterflies (option half_pipeline = 2, BASELINE config 5's "f16 FFT
+// pipeline"): the same three passes on h2 points.  A row is 32 KB in LDS (8 bytes per pair of
+// points), a thread's 32 points are 32 registers.  Range: the stored row is multiplied by `pre`
+// (2^-7) on the way in, so that the forward spectrum of full-scale input stays below f16's 65504,
+// and the needle spectrum arrives scaled to an rms of 1/8 per bin (`hscale`); K3 divides both out
+// in f32.  LDS layout: the f32 kernel's, in 8-byte elements, with 16 elements of padding per
+// 256 so that the two 16-lane halves of a 32-lane access group sit 32 banks apart.
+__device__ __forceinline__ unsigned h2_bits(h2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ h2 bits_h2(unsigned u) { return __builtin_bit_cast(h2, u); }
+constexpr int kK2hSlab = 272;                  // 8-byte elements per a' (256 + 16)
+constexpr int kK2hLds = 16 * kK2hSlab * 8;     // 34 816 bytes
+
+__global__ void __launch_bounds__(256, 3)
+k2_rows_h16(unsigned* __restrict__ work, const float2* __restrict__ hc, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
+            float hscale, float pre) {
+    extern __shared__ float4 lds4[];
+    uint2* ldsu = reinterpret_cast<uint2*>(lds4);
+    unsigned row, slot;
+    k2_place(npairs, row, slot);
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 4);
+    const __amdgpu_buffer_rsrc_t rdst = dst ? make_rsrc(dst + row_off, kN2 * 4) : rrow;   // in place, or a second work matrix
+    const K2Lane k = k2_lane(pl);
+    const int t = k.t, hi = k.hi, cp = k.cp;
+    h2 x0[16], x1[16];
+    {
+        const h2 p2 = (h2){(_Float16)pre, (_Float16)pre};
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
+            const uint2 v = buf_load_u2(rrow, k.voff / 2, a * 2048);
+            x0[a] = bits_h2(v.x) * p2;
+            x1[a] = bits_h2(v.y) * p2;
+        }
+    }
+    // ---- pass 1 over a ----
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    twiddle_brev<16, false>(x0, k.wj0);
+    twiddle_brev<16, false>(x1, k.wj1);
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap)
+        ldsu[ap * kK2hSlab + t] = make_uint2(h2_bits(x0[brev<16>(ap)]), h2_bits(x1[brev<16>(ap)]));
+    __syncthreads();
+    // ---- pass 2 over b ----
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const uint2 v = ldsu[hi * kK2hSlab + b * 16 + cp];
+        x0[b] = bits_h2(v.x);
+        x1[b] = bits_h2(v.y);
+    }
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    twiddle_brev<16, false>(x0, k.wc0);
+    twiddle_brev<16, false>(x1, k.wc1);
+    wave_sync_lds();   // wave-local exchange: slab hi belongs to the wavefront of the threads with that hi
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp)   // row u = hi*16 + b' of the slab, slot cp ^ b'
+        ldsu[hi * kK2hSlab + bp * 16 + (cp ^ bp)] = make_uint2(h2_bits(x0[brev<16>(bp)]), h2_bits(x1[brev<16>(bp)]));
+    wave_sync_lds();
+    // the needle-spectrum row, requested where only the 32 points of pass 3 are live
+    float4 h[16];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + (size_t)row * (kN2 / 2), kN2 * 8);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, k.voff, i * 4096);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- pass 3 over c: thread owns row u = t ----
+    h2 z[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint2 v = ldsu[hi * kK2hSlab + cp * 16 + (i ^ cp)];
+        z[2 * i] = bits_h2(v.x);
+        z[2 * i + 1] = bits_h2(v.y);
+    }
+    dif<32, false>(z);
+    // ---- multiply (pairwise_mult_in_place, audio_matcher.rs:432-438) ----
+    h2 q[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        q[brev<32>(2 * i)] = cmul(z[2 * i], to_h2(make_float2(h[i].x * hscale, h[i].y * hscale)));
+        q[brev<32>(2 * i + 1)] = cmul(z[2 * i + 1], to_h2(make_float2(h[i].z * hscale, h[i].w * hscale)));
+    }
+    // ---- inverse pass 3 ----
+    dif<32, true>(q);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        ldsu[hi * kK2hSlab + cp * 16 + (i ^ cp)] = make_uint2(h2_bits(q[brev<32>(2 * i)]), h2_bits(q[brev<32>(2 * i + 1)]));
+    wave_sync_lds();
+    // ---- inverse pass 2 ----
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) {
+        const uint2 v = ldsu[hi * kK2hSlab + bp * 16 + (cp ^ bp)];
+        x0[bp] = bits_h2(v.x);
+        x1[bp] = bits_h2(v.y);
+    }
+    twiddle_nat<16, true>(x0, k.wc0);
+    twiddle_nat<16, true>(x1, k.wc1);
+    dif<16, true>(x0);
+    dif<16, true>(x1);
+    wave_sync_lds();
+#pragma unroll
+    for (int b = 0; b < 16; ++b)
+        ldsu[hi * kK2hSlab + b * 16 + cp] = make_uint2(h2_bits(x0[brev<16>(b)]), h2_bits(x1[brev<16>(b)]));
+    __syncthreads();
+    // ---- inverse pass 1 ----
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) {
+        const uint2 v = ldsu[ap * kK2hSlab + t];
+        x0[ap] = bits_h2(v.x);
+        x1[ap] = bits_h2(v.y);
+    }
+    twiddle_nat<16, true>(x0, k.wj0);
+    twiddle_nat<16, true>(x1, k.wj1);
+    dif<16, true>(x0);
+    dif<16, true>(x1);
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+        buf_store_u2(rdst, k.voff / 2, a * 2048, make_uint2(h2_bits(x0[brev<16>(a)]), h2_bits(x1[brev<16>(a)])));
+}
+
 // K2 for a group of needles against one haystack (am_match_multi_device, BASELINE
 // config 4): the row is read and transformed ONCE; every needle of the group then
 // multiplies that spectrum with its own and runs its own inverse transform into its
@@ -987,7 +1147,7 @@ constexpr int kC512Slab3 = 32 * 16 + 16;
 __device__ __forceinline__ int c512_idx3(int ap, int b, int cp) { return ap * kC512Slab3 + b * 16 + cp; }
 static_assert((15 * kC512Slab3 + 31 * 16 + 16) * 8 <= kC512Lds, "K3's exchange fits the kernel's LDS");
 
-template <int KIND>
+template <int KIND, bool HALF>
 __global__ void __launch_bounds__(512, 2)
 k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
@@ -1060,6 +1220,15 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     // W_N^(n2*k1) = W_N^(n2*k10) * (W_N^(32*n2))^beta
     twiddle_chain<16, false, true>(y0, base0, step0);
     twiddle_chain<16, false, true>(y1, base1, step1);
+    if (HALF) {
+        uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bt = 0; bt < 16; ++bt) {
+            const size_t k1 = (size_t)(k10 + 32 * bt);
+            out2[k1 * (kN2 / 2)] = make_uint2(pack_h2(y0[brev<16>(bt)]), pack_h2(y1[brev<16>(bt)]));
+        }
+        return;
+    }
     float4* __restrict__ out4 = reinterpret_cast<float4*>(work + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
 #pragma unroll
     for (int bt = 0; bt < 16; ++bt) {
@@ -1069,6 +1238,7 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
+template <bool HALF>
 __global__ void __launch_bounds__(512, 2)
 k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1087,12 +1257,22 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned n2 = (unsigned)n2_0 + 2u * (unsigned)cp;
     float2 x0[16], x1[16];
-    const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+    if (HALF) {
+        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
 #pragma unroll
-    for (int bt = 0; bt < 16; ++bt) {   // rows k1 = k10 + 32*beta
-        const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(k10 + 32 * bt) * (kN2 / 2));
-        x0[bt] = make_float2(v.x, v.y);
-        x1[bt] = make_float2(v.z, v.w);
+        for (int bt = 0; bt < 16; ++bt) {
+            const uint2 v = in2[(size_t)(k10 + 32 * bt) * (kN2 / 2)];
+            x0[bt] = unpack_h2(v.x);
+            x1[bt] = unpack_h2(v.y);
+        }
+    } else {
+        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bt = 0; bt < 16; ++bt) {   // rows k1 = k10 + 32*beta
+            const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(k10 + 32 * bt) * (kN2 / 2));
+            x0[bt] = make_float2(v.x, v.y);
+            x1[bt] = make_float2(v.z, v.w);
+        }
     }
     const K3Edges ed = k3_edges(job, scan, blkA, blkB);
     const float2 w512 = pl.tw1[hi];
@@ -1388,15 +1568,19 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k1_cols_fwd_r16<1, false>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<0, true>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<1, true>), kR16LdsK1)
-    AM_SET_LDS(k1_cols_fwd_c512<0>, kC512Lds)
-    AM_SET_LDS(k1_cols_fwd_c512<1>, kC512Lds)
-    AM_SET_LDS(k3_cols_inv_c512, kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<0, false>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<1, false>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<0, true>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<1, true>), kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512<false>, kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512<true>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_r16<false>, kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_r16<true>, kR16LdsK3)
     AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<false, true>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
     AM_SET_LDS(k2_rows_r16_group, kR16Lds)
+    AM_SET_LDS(k2_rows_h16, kK2hLds)
 #undef AM_SET_LDS
     return hipSuccess;
 }
@@ -1405,8 +1589,13 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     const bool pcm = job.src_kind == 1;
     if (plan_is_c512(pl)) {
-        if (pcm) hipLaunchKernelGGL(k1_cols_fwd_c512<1>, grid, dim3(512), kC512Lds, st, job, work, pl);
-        else hipLaunchKernelGGL(k1_cols_fwd_c512<0>, grid, dim3(512), kC512Lds, st, job, work, pl);
+        if (half) {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, true>), grid, dim3(512), kC512Lds, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, true>), grid, dim3(512), kC512Lds, st, job, work, pl);
+        } else {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, false>), grid, dim3(512), kC512Lds, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, false>), grid, dim3(512), kC512Lds, st, job, work, pl);
+        }
     } else if (plan_is_r16(pl)) {
         if (half) {
             if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
@@ -1424,10 +1613,13 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
 }
 
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst,
-                     bool half, float hscale) {
+                     int half, float hscale, float pre) {
     const dim3 grid(1u << pl.logN1, npairs);
     if (plan_k2_is_r16(pl)) {
-        if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+        if (half == 2) {
+            hipLaunchKernelGGL(k2_rows_h16, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st,
+                               reinterpret_cast<unsigned*>(work), hc, reinterpret_cast<unsigned*>(dst), pl, (unsigned)npairs, hscale, pre);
+        } else if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
         else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                 dst, pl, (unsigned)npairs, 1.0f);
@@ -1464,8 +1656,10 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_c512(pl)) {
-        hipLaunchKernelGGL(k3_cols_inv_c512, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
-                           pl, out_scale, scan);
+        if (half) hipLaunchKernelGGL(k3_cols_inv_c512<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+                                     pl, out_scale, scan);
+        else hipLaunchKernelGGL(k3_cols_inv_c512<false>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+                                pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                                      pl, out_scale, scan);

@@ -49,7 +49,7 @@ struct Segment {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half = false);
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
-                     bool half = false, float hscale = 1.0f);
+                     int half = 0, float hscale = 1.0f, float pre = 1.0f);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
 // A group of needles sharing one forward row transform (r16 rows, f32 storage only):
 // needle j multiplies with hc[j] and writes its inverse rows to dst[j].

@@ -133,8 +133,9 @@ def parse_args():
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU sample (0 = three per thread, at most the whole hour)")
     ap.add_argument("--log-n", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (experiments)")
-    ap.add_argument("--half-pipeline", action="store_true",
-                    help="BASELINE config 5 precision: half-precision storage of the work matrix (not the headline)")
+    ap.add_argument("--half-pipeline", type=int, nargs="?", const=1, default=0,
+                    help="BASELINE config 5 precision (not the headline): 1 = work matrix stored as f16, "
+                         "2 = K2's butterflies in packed f16 as well")
     return ap.parse_args()
 
 
@@ -280,7 +281,7 @@ def main():
     if args.log_n:
         am.set_option("log_n", args.log_n)
     if args.half_pipeline:
-        am.set_option("half_pipeline", 1)
+        am.set_option("half_pipeline", args.half_pipeline)
     for kv in args.opt:
         k_, v_ = kv.split("=")
         am.set_option(k_, int(v_))
@@ -413,7 +414,7 @@ def main():
         "metric": METRIC, "value": value, "unit": "samples/s", "n_gpus": R.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f32 (work matrix stored as f16)" if args.half_pipeline else "f32",
+        "dtype": {0: "f32", 1: "f32 (work matrix stored as f16)", 2: "f16 row butterflies, f16 work matrix, f32 column passes"}[min(args.half_pipeline, 2)],
         "data": "synthetic",
         "config": {"workload": (f"1 x 10 s mono 44.1 kHz f32 needle vs {args.total_haystacks} x 1 h haystacks per step in total, "
                                 f"haystack k on rank k mod N, resident in HBM (BASELINE configs[2])" if strong else

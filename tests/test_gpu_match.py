@@ -414,10 +414,12 @@ def test_degenerate_signals_terminate(gpu, oracle):
         assert isinstance(zero.match(oracle.synth_uniform(5, 2, 0, 30 * sr), p), list)
 
 
-def test_half_pipeline_config5(gpu, oracle):
+@pytest.mark.parametrize("level", [1, 2])
+def test_half_pipeline_config5(gpu, oracle, level):
     """BASELINE config 5: 48 kHz interleaved i16 stereo through the half-precision
-    pipeline (work matrix stored as f16).  SURVEY 7: offset parity is the promise;
-    scores are additionally checked to 1e-3."""
+    pipeline (level 1: work matrix stored as f16, f32 butterflies; level 2: K2's butterflies
+    in packed f16 as well).  SURVEY 7: offset parity is the promise; scores are additionally
+    checked to 1e-3."""
     sr = 48000
     rng = np.random.default_rng(77)
     s, h = 10 * sr, 250 * sr
@@ -433,7 +435,7 @@ def test_half_pipeline_config5(gpu, oracle):
     p = cfg.params(sr, gpu.Scale.LIB)
     exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
     assert len(exp) == 4
-    gpu.set_option("half_pipeline", 1)
+    gpu.set_option("half_pipeline", level)
     try:
         algo = gpu.HipConvolve.from_pcm16(needle_lr)
         for _ in range(2):
@@ -449,7 +451,7 @@ def test_half_pipeline_config5(gpu, oracle):
         err = float(np.abs(sc - ref).max())
     finally:
         gpu.set_option("half_pipeline", 0)
-    print("half pipeline max score error", err)
+    print("half pipeline level", level, "max score error", err)
 
 
 def test_shutdown_releases_and_recovers(gpu, oracle):

@@ -33,6 +33,23 @@ __global__ void __launch_bounds__(256, 2) row_copy(float4* a, float4* b) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { v[i].x += 1.0f; st4<SA>(rd, threadIdx.x * 16u, i * 4096, v[i]); }
 }
+// The same row with `spin` rounds of 64 dependent FMAs per thread between the loads and the
+// stores (K2 issues ~3400 VALU instructions per wave: spin = 50), at a chosen LDS footprint,
+// i.e. at 2, 3 or 4 workgroups per CU: what the in-place stream gives a kernel that computes.
+__global__ void __launch_bounds__(256, 2) row_work(float4* a, int spin) {
+    extern __shared__ float4 lds[];
+    const size_t base = (size_t)blockIdx.x * 4096;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a + base, 65536);
+    f32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ld4<0>(rs, threadIdx.x * 16u, i * 4096);
+    for (int k = 0; k < spin; ++k) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = v[i] * 1.0001f + v[(i + 1) & 15];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st4<0>(rs, threadIdx.x * 16u, i * 4096, v[i]);
+}
 // K3 / K1 shape: 32 columns x 256 rows of a [256][8192] float2 matrix per workgroup
 template <int LA, int SA, int MODE>   // 0 read only, 1 write only
 __global__ void __launch_bounds__(256, 3) col_rw(float4* m, float* sink) {
@@ -121,6 +138,12 @@ int main() {
     // K2 shape
     ROW(0, 0, true); ROW(2, 0, true); ROW(0, 2, true); ROW(2, 2, true); ROW(16, 0, true); ROW(0, 16, true); ROW(18, 18, true); ROW(1, 0, true); ROW(3, 2, true);
     ROW(0, 0, false); ROW(2, 2, false); ROW(2, 0, false); ROW(0, 2, false);
+    // K2 shape with compute, by occupancy (LDS footprint 64 / 52 / 40 / 32 KB = 2 / 3 / 4 / 5 workgroups per CU)
+    hipFuncSetAttribute((const void*)row_work, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int spin : {0, 25, 50}) for (int lds : {65536, 53248, 40960, 32768}) {
+        float t = timeit([&]{ row_work<<<nwg, 256, lds>>>(A, spin); });
+        printf("row in place + %2d x 64 FMA, LDS %5d B : %.3f ms  %.2f TB/s\n", spin, lds, t, 2 * gb / t);
+    }
     // K3 read / K1 write shapes
     COL(0, 0, 0); COL(2, 0, 0); COL(16, 0, 0); COL(18, 0, 0); COL(1, 0, 0);
     COL(0, 0, 1); COL(0, 2, 1); COL(0, 16, 1); COL(0, 18, 1);
