@@ -273,6 +273,7 @@ struct am_needle {
     size_t n = 0;
     float inv_autocorr = 0.f;
     std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
+    std::map<int, unsigned*> spectra16;   // logN -> the same as scaled __half2 points (half_pipeline = 2)
     // lowest chunk minimum of the scores seen so far (index 0: unscaled, 1: AM_SCALE_LIB);
     // drives the raw-score write threshold of the fused scan
     bool have_min[2] = {false, false};
@@ -351,6 +352,27 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
     if (e != hipSuccess) { (void)hipFree(hc); return hip_fail(e, "needle spectrum"); }
     h->spectra[key] = hc;
     *out = hc;
+    return AM_OK;
+}
+
+// half_pipeline = 2: the spectrum as __half2 points times `hscale` (fixed per needle and plan)
+static int needle_spectrum16(am_needle* h, const Plan* pl, float hscale, const float2** out) {
+    const int key = pl->dev.logN;
+    auto it = h->spectra16.find(key);
+    if (it != h->spectra16.end()) { *out = reinterpret_cast<const float2*>(it->second); return AM_OK; }
+    const float2* hc = nullptr;
+    int rc = needle_spectrum(h, pl, &hc);
+    if (rc) return rc;
+    Ctx* c = h->ctx;
+    const size_t N = (size_t)1 << pl->dev.logN;
+    unsigned* h16 = nullptr;
+    AM_HIP(hipMalloc((void**)&h16, N * sizeof(unsigned)));
+    hipError_t e;
+    { ProfScope ps(c, KN_OTHER); e = launch_spectrum_to_half(c->stream, hc, (long long)N, hscale, h16); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(h16); return hip_fail(e, "needle spectrum (f16)"); }
+    h->spectra16[key] = h16;
+    *out = reinterpret_cast<const float2*>(h16);
     return AM_OK;
 }
 
@@ -457,6 +479,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     const HalfScale hs = half_scale(h, o, pl->dev);
     const bool half = hs.level != 0;
     const float k3scale = hs.k3(factor);
+    if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hc))) return rc;
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
@@ -922,6 +945,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         }
         const float factor = scale_factor(h, p->scale, 1);
         const HalfScale hs = half_scale(h, o, pl->dev);
+        if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hcs[k]))) return rc;
         if (group == 1) { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, hs.level, hs.hscale, hs.pre)); }
         { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, inv_rows, pl->dev,
                                                   hs.k3(factor), cfg, half)); }
@@ -1074,6 +1098,7 @@ void am_needle_destroy(am_needle* h) {
         (void)hipSetDevice(h->ctx->device);
         (void)hipStreamSynchronize(h->ctx->stream);
         for (auto& kv : h->spectra) (void)hipFree(kv.second);
+        for (auto& kv : h->spectra16) (void)hipFree(kv.second);
         if (h->d_needle) (void)hipFree(h->d_needle);
     }
     delete h;

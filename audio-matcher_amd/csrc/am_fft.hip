@@ -660,9 +660,12 @@ __device__ __forceinline__ h2 bits_h2(unsigned u) { return __builtin_bit_cast(h2
 constexpr int kK2hSlab = 272;                  // 8-byte elements per a' (256 + 16)
 constexpr int kK2hLds = 16 * kK2hSlab * 8;     // 34 816 bytes
 
-__global__ void __launch_bounds__(256, 3)
-k2_rows_h16(unsigned* __restrict__ work, const float2* __restrict__ hc, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
-            float hscale, float pre) {
+#ifndef AM_K2H_WGS
+#define AM_K2H_WGS 3   // waves per SIMD the register allocation has to allow (3 and 4 measure the same; 4 spills)
+#endif
+__global__ void __launch_bounds__(256, AM_K2H_WGS)
+k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
+            float pre) {
     extern __shared__ float4 lds4[];
     uint2* ldsu = reinterpret_cast<uint2*>(lds4);
     unsigned row, slot;
@@ -708,12 +711,12 @@ k2_rows_h16(unsigned* __restrict__ work, const float2* __restrict__ hc, unsigned
         ldsu[hi * kK2hSlab + bp * 16 + (cp ^ bp)] = make_uint2(h2_bits(x0[brev<16>(bp)]), h2_bits(x1[brev<16>(bp)]));
     wave_sync_lds();
     // the needle-spectrum row, requested where only the 32 points of pass 3 are live
-    float4 h[16];
+    uint2 h[16];
     __builtin_amdgcn_sched_barrier(0);
     {
-        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + (size_t)row * (kN2 / 2), kN2 * 8);
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(hc16 + (size_t)row * kN2, kN2 * 4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) h[i] = buf_load4(rh, k.voff, i * 4096);
+        for (int i = 0; i < 16; ++i) h[i] = buf_load_u2(rh, k.voff / 2, i * 2048);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- pass 3 over c: thread owns row u = t ----
@@ -729,8 +732,8 @@ k2_rows_h16(unsigned* __restrict__ work, const float2* __restrict__ hc, unsigned
     h2 q[32];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        q[brev<32>(2 * i)] = cmul(z[2 * i], to_h2(make_float2(h[i].x * hscale, h[i].y * hscale)));
-        q[brev<32>(2 * i + 1)] = cmul(z[2 * i + 1], to_h2(make_float2(h[i].z * hscale, h[i].w * hscale)));
+        q[brev<32>(2 * i)] = cmul(z[2 * i], bits_h2(h[i].x));
+        q[brev<32>(2 * i + 1)] = cmul(z[2 * i + 1], bits_h2(h[i].y));
     }
     // ---- inverse pass 3 ----
     dif<32, true>(q);
@@ -768,6 +771,15 @@ k2_rows_h16(unsigned* __restrict__ work, const float2* __restrict__ hc, unsigned
 #pragma unroll
     for (int a = 0; a < 16; ++a)
         buf_store_u2(rdst, k.voff / 2, a * 2048, make_uint2(h2_bits(x0[brev<16>(a)]), h2_bits(x1[brev<16>(a)])));
+}
+
+__global__ void __launch_bounds__(256) spectrum_to_half_kernel(const float2* __restrict__ hc, long long n, float scale, unsigned* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        out[i] = h2_bits(to_h2(make_float2(hc[i].x * scale, hc[i].y * scale)));
+}
+hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out) {
+    hipLaunchKernelGGL(spectrum_to_half_kernel, dim3(2048), dim3(256), 0, st, hc, n, scale, out);
+    return hipGetLastError();
 }
 
 // K2 for a group of needles against one haystack (am_match_multi_device, BASELINE
@@ -1148,7 +1160,9 @@ __device__ __forceinline__ int c512_idx3(int ap, int b, int cp) { return ap * kC
 static_assert((15 * kC512Slab3 + 31 * 16 + 16) * 8 <= kC512Lds, "K3's exchange fits the kernel's LDS");
 
 template <int KIND, bool HALF>
-__global__ void __launch_bounds__(512, 2)
+// (second argument: waves per SIMD.  The f32 forms use 124 / 126 VGPRs and fit twice per CU as they are; the
+// half-storage form would take 130 and run alone on its CU, so it is held to 128)
+__global__ void __launch_bounds__(512, HALF ? 4 : 2)
 k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
     float2* lds2 = reinterpret_cast<float2*>(lds4);
@@ -1239,7 +1253,7 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
 }
 
 template <bool HALF>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, 2)   // (uses 119 / 117 VGPRs: two workgroups per CU; a tighter bound makes the allocator spill)
 k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
     float2* lds2 = reinterpret_cast<float2*>(lds4);
@@ -1618,7 +1632,8 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
     if (plan_k2_is_r16(pl)) {
         if (half == 2) {
             hipLaunchKernelGGL(k2_rows_h16, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st,
-                               reinterpret_cast<unsigned*>(work), hc, reinterpret_cast<unsigned*>(dst), pl, (unsigned)npairs, hscale, pre);
+                               reinterpret_cast<unsigned*>(work), reinterpret_cast<const unsigned*>(hc), reinterpret_cast<unsigned*>(dst),
+                               pl, (unsigned)npairs, pre);
         } else if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
         else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,

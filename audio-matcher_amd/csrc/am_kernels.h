@@ -50,6 +50,8 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
                      int half = 0, float hscale = 1.0f, float pre = 1.0f);
+// half = 2: hc points at the __half2 form of the spectrum (launch_spectrum_to_half), hscale already in it
+hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
 // A group of needles sharing one forward row transform (r16 rows, f32 storage only):
 // needle j multiplies with hc[j] and writes its inverse rows to dst[j].
