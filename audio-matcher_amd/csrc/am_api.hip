@@ -477,7 +477,6 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     // half-precision storage of the work matrix: K2 normalises by the needle
     // energy (times a fixed gain) so that stored values sit mid-range in f16
     const HalfScale hs = half_scale(h, o, pl->dev);
-    const bool half = hs.level != 0;
     const float k3scale = hs.k3(factor);
     if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hc))) return rc;
     Job job{};
@@ -492,11 +491,11 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     for (long long first = pair_lo; first < pair_hi; first += ppg) {
         const int np = (int)std::min(ppg, pair_hi - first);
         job.first_pair = (int)first;
-        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, half)); }
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, hs.level)); }
         { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre)); }
         if (!waited && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
         waited = true;
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, half)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, hs.level)); }
     }
     return AM_OK;
 }
@@ -898,7 +897,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
     for (size_t k = 0; k < nn; ++k)
         if ((rc = needle_spectrum(needles[k], pl, &hcs[k]))) return rc;   // may use c->work: before it is filled
     if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
-    const bool half = o.half && (plan_is_r16(pl->dev) || plan_is_c512(pl->dev));
+    const int half = (o.half && (plan_is_r16(pl->dev) || plan_is_c512(pl->dev))) ? (o.half >= 2 ? 2 : 1) : 0;
     // needles are taken in groups that share the forward row transforms of K2
     const size_t group = (!half && plan_k2_has_group(pl->dev))
         ? (size_t)std::min<long long>(std::max<long long>(1, o.needle_group), kMaxNeedleGroup) : 1;

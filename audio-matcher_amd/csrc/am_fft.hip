@@ -106,6 +106,9 @@ __device__ __forceinline__ h2 cmul(h2 a, h2 b) {
 __device__ __forceinline__ h2 mul_neg_i(h2 a) { return (h2){a.y, -a.x}; }
 __device__ __forceinline__ h2 mul_pos_i(h2 a) { return (h2){-a.y, a.x}; }
 __device__ __forceinline__ h2 to_h2(float2 v) { return (h2){(_Float16)v.x, (_Float16)v.y}; }
+__device__ __forceinline__ float2 to_f2(h2 v) { return make_float2((float)v.x, (float)v.y); }
+__device__ __forceinline__ unsigned h2_bits(h2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ h2 bits_h2(unsigned u) { return __builtin_bit_cast(h2, u); }
 template <bool INV>
 __device__ __forceinline__ h2 mul_w32(h2 d, int idx) {
     if (idx == 0) return d;
@@ -160,6 +163,38 @@ __device__ __forceinline__ void twiddle_apply(h2* x, float2 w) {
         const float2 v = cmul(pw[(e + 1) / 2], pw[e / 2]);
         if (e <= R / 2) pw[e] = v;
         x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], to_h2(v));
+    }
+}
+// two half-precision columns that take the same twiddles (the column passes: the pass twiddle does
+// not depend on the column)
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_apply2(h2* x0, h2* x1, float2 w) {
+    float2 pw[R / 2 + 1];
+    if (CONJ) w.y = -w.y;
+    pw[1] = w;
+    {
+        const h2 wh = to_h2(w);
+        x0[BREV ? brev<R>(1) : 1] = cmul(x0[BREV ? brev<R>(1) : 1], wh);
+        x1[BREV ? brev<R>(1) : 1] = cmul(x1[BREV ? brev<R>(1) : 1], wh);
+    }
+#pragma unroll
+    for (int e = 2; e < R; ++e) {
+        const float2 v = cmul(pw[(e + 1) / 2], pw[e / 2]);
+        if (e <= R / 2) pw[e] = v;
+        const h2 vh = to_h2(v);
+        x0[BREV ? brev<R>(e) : e] = cmul(x0[BREV ? brev<R>(e) : e], vh);
+        x1[BREV ? brev<R>(e) : e] = cmul(x1[BREV ? brev<R>(e) : e], vh);
+    }
+}
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_chain(h2* x, float2 base, float2 step) {
+    if (CONJ) { base.y = -base.y; step.y = -step.y; }
+    float2 c = base;
+    x[0] = cmul(x[0], to_h2(c));
+#pragma unroll
+    for (int e = 1; e < R; ++e) {
+        c = cmul(c, step);
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], to_h2(c));
     }
 }
 // x[idx(e)] *= base * step^e (or the conjugates), e = 0..R-1, as one running
@@ -655,8 +690,6 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
 // and the needle spectrum arrives scaled to an rms of 1/8 per bin (`hscale`); K3 divides both out
 // in f32.  LDS layout: the f32 kernel's, in 8-byte elements, with 16 elements of padding per
 // 256 so that the two 16-lane halves of a 32-lane access group sit 32 banks apart.
-__device__ __forceinline__ unsigned h2_bits(h2 v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ h2 bits_h2(unsigned u) { return __builtin_bit_cast(h2, u); }
 constexpr int kK2hSlab = 272;                  // 8-byte elements per a' (256 + 16)
 constexpr int kK2hLds = 16 * kK2hSlab * 8;     // 34 816 bytes
 
@@ -1159,7 +1192,7 @@ constexpr int kC512Slab3 = 32 * 16 + 16;
 __device__ __forceinline__ int c512_idx3(int ap, int b, int cp) { return ap * kC512Slab3 + b * 16 + cp; }
 static_assert((15 * kC512Slab3 + 31 * 16 + 16) * 8 <= kC512Lds, "K3's exchange fits the kernel's LDS");
 
-template <int KIND, bool HALF>
+template <int KIND, int HALF>   // HALF: 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and f16 butterflies
 // (second argument: waves per SIMD.  The f32 forms use 124 / 126 VGPRs and fit twice per CU as they are; the
 // half-storage form would take 130 and run alone on its CU, so it is held to 128)
 __global__ void __launch_bounds__(512, HALF ? 4 : 2)
@@ -1204,6 +1237,37 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
             x0[a] = make_float2(va.x, vb.x);
             x1[a] = make_float2(va.y, vb.y);
         }
+    }
+    if constexpr (HALF == 2) {
+        // the same transform on packed half-precision points; both columns of the pair cross LDS
+        // together (8 bytes per element, as one f32 column does): one exchange instead of two
+        h2 hx0[16], hx1[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) { hx0[a] = to_h2(x0[a]); hx1[a] = to_h2(x1[a]); }
+        dif<16, false>(hx0);
+        dif<16, false>(hx1);
+        twiddle_apply2<16, false, true>(hx0, hx1, w512);
+        uint2* ldsu = reinterpret_cast<uint2*>(lds4);
+#pragma unroll
+        for (int a2 = 0; a2 < 16; ++a2) ldsu[c512_idx(a2, hi, cp)] = make_uint2(h2_bits(hx0[brev<16>(a2)]), h2_bits(hx1[brev<16>(a2)]));
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint2 lo = ldsu[c512_idx(ap, b, cp)], up = ldsu[c512_idx(ap, b + 16, cp)];
+            hx0[b] = half ? mul_w32<false>(csub(bits_h2(lo.x), bits_h2(up.x)), b) : cadd(bits_h2(lo.x), bits_h2(up.x));
+            hx1[b] = half ? mul_w32<false>(csub(bits_h2(lo.y), bits_h2(up.y)), b) : cadd(bits_h2(lo.y), bits_h2(up.y));
+        }
+        dif<16, false>(hx0);
+        dif<16, false>(hx1);
+        twiddle_chain<16, false, true>(hx0, base0, step0);
+        twiddle_chain<16, false, true>(hx1, base1, step1);
+        uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bt = 0; bt < 16; ++bt) {
+            const size_t k1 = (size_t)(k10 + 32 * bt);
+            out2[k1 * (kN2 / 2)] = make_uint2(h2_bits(hx0[brev<16>(bt)]), h2_bits(hx1[brev<16>(bt)]));
+        }
+        return;
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
@@ -1252,7 +1316,7 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <bool HALF>
+template <int HALF>   // as in k1_cols_fwd_c512
 __global__ void __launch_bounds__(512, 2)   // (uses 119 / 117 VGPRs: two workgroups per CU; a tighter bound makes the allocator spill)
 k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1271,6 +1335,57 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned n2 = (unsigned)n2_0 + 2u * (unsigned)cp;
     float2 x0[16], x1[16];
+    if constexpr (HALF == 2) {
+        // first pass (pipeline twiddle, 16-point transform over beta, the W_32 branch factors) and the
+        // exchange on packed half-precision points, both columns in one exchange; the second pass and
+        // everything behind it in f32, so that no score is rounded to f16 on the way out
+        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
+        h2 hx0[16], hx1[16];
+#pragma unroll
+        for (int bt = 0; bt < 16; ++bt) {
+            const uint2 v = in2[(size_t)(k10 + 32 * bt) * (kN2 / 2)];
+            hx0[bt] = bits_h2(v.x);
+            hx1[bt] = bits_h2(v.y);
+        }
+        const K3Edges ed = k3_edges(job, scan, blkA, blkB);
+        const float2 w512 = pl.tw1[hi];
+        {
+            const float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
+            const float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
+            const float2 step0 = tw_big(pl, (n2 * 32u) & maskN);
+            const float2 step1 = tw_big(pl, ((n2 + 1u) * 32u) & maskN);
+            twiddle_chain<16, true, false>(hx0, base0, step0);
+            twiddle_chain<16, true, false>(hx1, base1, step1);
+        }
+        dif<16, true>(hx0);
+        dif<16, true>(hx1);
+        if (half) {
+#pragma unroll
+            for (int b = 1; b < 16; ++b) {
+                hx0[brev<16>(b)] = mul_w32<true>(hx0[brev<16>(b)], b);
+                hx1[brev<16>(b)] = mul_w32<true>(hx1[brev<16>(b)], b);
+            }
+        }
+        const float sgn = hi >= 16 ? -1.0f : 1.0f;
+        const int bb = hi & 15;
+        uint2* ldsu = reinterpret_cast<uint2*>(lds4);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) ldsu[c512_idx3(ap, b + 16 * half, cp)] = make_uint2(h2_bits(hx0[brev<16>(b)]), h2_bits(hx1[brev<16>(b)]));
+        __syncthreads();
+#pragma unroll
+        for (int a2 = 0; a2 < 16; ++a2) {
+            const uint2 u = ldsu[c512_idx3(a2, bb, cp)], v = ldsu[c512_idx3(a2, bb + 16, cp)];
+            const float2 u0 = to_f2(bits_h2(u.x)), v0 = to_f2(bits_h2(v.x)), u1 = to_f2(bits_h2(u.y)), v1 = to_f2(bits_h2(v.y));
+            x0[a2] = make_float2(fmaf(sgn, v0.x, u0.x), fmaf(sgn, v0.y, u0.y));
+            x1[a2] = make_float2(fmaf(sgn, v1.x, u1.x), fmaf(sgn, v1.y, u1.y));
+        }
+        twiddle_nat<16, true>(x0, w512);
+        twiddle_nat<16, true>(x1, w512);
+        dif<16, true>(x0);
+        dif<16, true>(x1);
+        k3_finish<5>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+        return;
+    }
     if (HALF) {
         const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
 #pragma unroll
@@ -1582,12 +1697,15 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k1_cols_fwd_r16<1, false>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<0, true>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_r16<1, true>), kR16LdsK1)
-    AM_SET_LDS((k1_cols_fwd_c512<0, false>), kC512Lds)
-    AM_SET_LDS((k1_cols_fwd_c512<1, false>), kC512Lds)
-    AM_SET_LDS((k1_cols_fwd_c512<0, true>), kC512Lds)
-    AM_SET_LDS((k1_cols_fwd_c512<1, true>), kC512Lds)
-    AM_SET_LDS(k3_cols_inv_c512<false>, kC512Lds)
-    AM_SET_LDS(k3_cols_inv_c512<true>, kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<0, 0>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<1, 0>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<0, 1>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<1, 1>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<0, 2>), kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<1, 2>), kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512<1>, kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512<2>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_r16<false>, kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_r16<true>, kR16LdsK3)
     AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
@@ -1599,16 +1717,19 @@ hipError_t fft_kernels_init() {
     return hipSuccess;
 }
 
-hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half) {
+hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, int half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     const bool pcm = job.src_kind == 1;
     if (plan_is_c512(pl)) {
-        if (half) {
-            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, true>), grid, dim3(512), kC512Lds, st, job, work, pl);
-            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, true>), grid, dim3(512), kC512Lds, st, job, work, pl);
+        if (half == 2) {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, 2>), grid, dim3(512), kC512Lds, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, 2>), grid, dim3(512), kC512Lds, st, job, work, pl);
+        } else if (half) {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, 1>), grid, dim3(512), kC512Lds, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, 1>), grid, dim3(512), kC512Lds, st, job, work, pl);
         } else {
-            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, false>), grid, dim3(512), kC512Lds, st, job, work, pl);
-            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, false>), grid, dim3(512), kC512Lds, st, job, work, pl);
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_c512<1, 0>), grid, dim3(512), kC512Lds, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_c512<0, 0>), grid, dim3(512), kC512Lds, st, job, work, pl);
         }
     } else if (plan_is_r16(pl)) {
         if (half) {
@@ -1668,12 +1789,14 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
 
 // scan.stats32 != nullptr only for the plans with a fused scan (plan_has_scan) and a 1024-aligned hop
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half) {
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (plan_is_c512(pl)) {
-        if (half) hipLaunchKernelGGL(k3_cols_inv_c512<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
-                                     pl, out_scale, scan);
-        else hipLaunchKernelGGL(k3_cols_inv_c512<false>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+        if (half == 2) hipLaunchKernelGGL(k3_cols_inv_c512<2>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+                                          pl, out_scale, scan);
+        else if (half) hipLaunchKernelGGL(k3_cols_inv_c512<1>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+                                          pl, out_scale, scan);
+        else hipLaunchKernelGGL(k3_cols_inv_c512<0>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
                                 pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
         if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,

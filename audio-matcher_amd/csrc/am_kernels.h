@@ -45,8 +45,9 @@ struct Segment {
     long long a, b;       // [a, b) in the score array
 };
 
-// half = store the work matrix as __half2 per point (N = 2^21 plan only)
-hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, bool half = false);
+// half: 0 = f32 work matrix; 1 = one __half2 per point, f32 butterflies; 2 = packed f16 butterflies too
+// (K2 on every plan, the column kernels on the 2^22 plan; the 2^21 column kernels keep f32 butterflies)
+hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, int half = 0);
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
                      int half = 0, float hscale = 1.0f, float pre = 1.0f);
@@ -73,7 +74,7 @@ struct ScanCfg {
     double inv_c;             // 1.0 / seg_c
 };
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan, bool half = false);
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half = 0);
 // needles of at most this many samples are correlated by direct summation (no transform)
 constexpr int kDirectMaxNeedle = 64;
 hipError_t launch_direct(hipStream_t st, const Job& job, const float* needle, int s, float out_scale);

@@ -521,3 +521,34 @@ def test_512_row_plan_on_pcm16_and_several_needles(gpu, oracle):
         assert [(g.start, g.end) for g in got] == [(g.start, g.end) for g in one]
         for g, o in zip(got, one):
             assert abs(g.height - o.height) < 2e-6 and abs(g.prominence - o.prominence) < 2e-6
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_half_pipeline_levels_on_both_plans_and_several_needles(gpu, oracle, level):
+    """Option half_pipeline on the shapes test_half_pipeline_config5 (tests/test_gpu_match.py) does not
+    reach: the N = 2^21 plan (5 s needle: level 2 there means K2's f16 butterflies between the f32
+    column kernels) and several needles against one haystack (K2 into a second work matrix) on both
+    plans; per handle, so that nothing leaks into other tests.  Offsets identical, scores to 1e-3."""
+    sr = 44100
+    for secs, seed in ((5.0, 71), (8.0, 72)):               # 220 500 samples: 2^21; 352 800 samples: 2^22
+        s = int(secs * sr)
+        needles = [oracle.synth_uniform(seed, 300 + k, 0, s) for k in range(2)]
+        hay = oracle.synth_uniform(seed, 1, 0, 130 * sr)
+        plants = [[int(12.25 * sr), int(91.0 * sr)], [int(47.5 * sr)]]
+        for n_, offs in zip(needles, plants):
+            for off in offs:
+                hay[off:off + s] += n_
+        cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=secs, distance_s=20.0, prominence=0.13)
+        p = cfg.params(sr, gpu.Scale.LIB)
+        algos = [gpu.HipConvolve(n_) for n_ in needles]
+        for a in algos:
+            a.set_option("half_pipeline", level)
+        buf = gpu.DeviceBuffer.from_numpy(0, hay)
+        exps = [oracle.calc_chunks(sr, hay, n_, p.chunk, p.overlap, 0.13, p.min_distance, 20.0) for n_ in needles]
+        assert [[e[0] for e in ex] for ex in exps] == plants
+        for _ in range(2):                                  # dense first call, then the sparse score path
+            for a, ex in zip(algos, exps):
+                assert_same(a.match_device(buf.ptr, hay.size, p), ex, tol=1e-3)
+        res = gpu.match_multi_device(algos, buf.ptr, hay.size, p)   # (takes the first handle's options)
+        for got, ex in zip(res, exps):
+            assert_same(got, ex, tol=1e-3)
