@@ -142,6 +142,8 @@ struct Ctx {
     // sits between the last kernel and the host's wake-up.
     HostBuf hdr;
     HostBuf spill;   // spill arena of the single-chunk passes (same kind of memory)
+    HostBuf badflag; // one word per haystack of a call: "some score was not finite"
+    DevBuf ranges, range_flags;   // work area of the non-finite-sample search (rare path)
     // the chunk list currently resident in `segs` (re-uploaded only when it changes)
     std::vector<Segment> segs_resident;
     // profiling
@@ -387,6 +389,7 @@ struct ScanRequest {
     // in: restrict the launch to the blocks that produce scores [range_a, range_b) (range_b = 0:
     // everything).  Used to redo single chunks with theta = -inf in place.
     long long range_a, range_b;
+    int* bad;                // in: host-visible word the summary kernels of the pick set when a score is not finite, or null
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
@@ -594,8 +597,9 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     if ((rc = bstats.ensure((size_t)ntiles * sizeof(float2)))) return rc;
     {
         ProfScope ps(c, KN_STATS, st);
-        if (d_stats32) AM_HIP(launch_stats_reduce(st, d_stats32, n_scores, (float2*)bstats.p));
-        else AM_HIP(launch_tile_stats(st, d_scores, n_scores, (float2*)bstats.p));
+        int* bad = scan ? scan->bad : nullptr;
+        if (d_stats32) AM_HIP(launch_stats_reduce(st, d_stats32, n_scores, (float2*)bstats.p, bad));
+        else AM_HIP(launch_tile_stats(st, d_scores, n_scores, (float2*)bstats.p, bad));
     }
     // hand-over area for chunks with many candidate tiles (per chunk of this launch; the picks
     // of one call run in stream order, so one area serves them all)
@@ -673,6 +677,47 @@ static inline const void* advance_src(const void* src, size_t elements) {
 // 1 / (sum(needle^2) * within.len()) depends on the window, so the windows of full
 // length share the main pass and every shorter window at the end of a haystack is
 // correlated on its own with its own factor.
+// Which chunks of a haystack are touched by non-finite samples: drop[i] = the chunk's own window
+// holds one (the reference's scores for it are NaN throughout: no peak); again[i] = its window is
+// clean but some of its scores came from a block pair that holds one.  One search kernel over the
+// sample ranges of all block pairs and all windows; rare path, synchronous.
+static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, size_t len, long long out_count,
+                              const std::vector<Segment>& segs, int s0, int s1,
+                              std::vector<char>* drop, std::vector<char>* again) {
+    Ctx* c = h->ctx;
+    const long long s = (long long)h->n;
+    const int nch = s1 - s0;
+    drop->assign(nch, 0); again->assign(nch, 0);
+    std::vector<Segment> ranges;
+    for (int i = s0; i < s1; ++i)       // the samples behind scores [a, b): a .. b + s - 2
+        ranges.push_back(Segment{segs[i].a, std::min<long long>((long long)len, segs[i].b + s - 1)});
+    Geometry g{};
+    long long npairs = 0;
+    if (!(h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0)) {   // (direct summation spreads nothing)
+        int rc = plan_geometry(h->n, out_count, o, &g);
+        if (rc) return rc;
+        npairs = g.npairs;
+        for (long long q = 0; q < npairs; ++q)   // blocks 2q, 2q+1 read samples [2q hop, (2q+2) hop + s - 1)
+            ranges.push_back(Segment{2 * q * g.hop, std::min<long long>((long long)len, (2 * q + 2) * g.hop + s - 1)});
+    }
+    int rc;
+    if ((rc = c->ranges.ensure(sizeof(Segment) * ranges.size()))) return rc;
+    if ((rc = c->range_flags.ensure(sizeof(int) * ranges.size()))) return rc;
+    AM_HIP(hipMemcpyAsync(c->ranges.p, ranges.data(), sizeof(Segment) * ranges.size(), hipMemcpyHostToDevice, c->stream));
+    AM_HIP(hipMemsetAsync(c->range_flags.p, 0, sizeof(int) * ranges.size(), c->stream));
+    AM_HIP(launch_nonfinite_ranges(c->stream, d_hay, (const Segment*)c->ranges.p, (int)ranges.size(), (int*)c->range_flags.p));
+    std::vector<int> flags(ranges.size(), 0);
+    AM_HIP(hipMemcpyAsync(flags.data(), c->range_flags.p, sizeof(int) * ranges.size(), hipMemcpyDeviceToHost, c->stream));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nch; ++i) {
+        if (flags[i]) { (*drop)[i] = 1; continue; }
+        const Segment sg = segs[s0 + i];
+        for (long long q = 0; q < npairs && !(*again)[i]; ++q)
+            if (flags[nch + q] && 2 * q * g.hop < sg.b && (2 * q + 2) * g.hop > sg.a) (*again)[i] = 1;
+    }
+    return AM_OK;
+}
+
 static int match_many(am_needle* h, const void* const* d_hays, const size_t* lens, size_t n_hay,
                       const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0,
                       size_t index_base = 0, size_t index_stride = 1) {
@@ -755,7 +800,14 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // second-pass window (those are correlated on their own, see below)
     std::vector<Segment> resident = segs;
     for (const Segment& sg : tail_segs) { Segment local; local.a = 0; local.b = sg.b - sg.a; resident.push_back(local); }
+    // and one local slice as long as a full chunk, for chunks that are correlated again on their
+    // own window (non-finite samples nearby, below); the pick clamps it to the scores there are
+    const int local_seg = (int)resident.size();
+    { Segment local; local.a = 0; local.b = std::max<long long>(scan.seg_d, 1); resident.push_back(local); }
     if ((rc = upload_segments(c, resident))) return rc;
+    if ((rc = c->badflag.ensure(sizeof(int) * n_hay))) return rc;
+    int* h_bad = static_cast<int*>(c->badflag.p);
+    memset(h_bad, 0, sizeof(int) * n_hay);
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     auto chunk_events = [&](size_t k, int stage) {
         if (hooks.chunk_fn)
@@ -774,6 +826,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
         scan.set = set;
         scan.before_k3 = (overlap && seq >= 2) ? c->ev_pick[set] : nullptr;
+        scan.bad = (src_kind == 0 && std::isfinite(factor)) ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
         if ((rc = run_correlation(h, o, d_hays[k], (long long)lens[k], 0, d_scores, out_count, factor,
                                   &scan, src_kind))) return rc;
         if (overlap) {
@@ -789,6 +842,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     if (overlap) AM_HIP(hipStreamSynchronize(c->stream2));
     scan.set = 0;
     scan.before_k3 = nullptr;
+    scan.bad = nullptr;
     int worst = AM_OK;
     std::vector<am_peak> all;
     const int spare_hdr = (int)nsegs;
@@ -796,13 +850,48 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         const int s0 = seg_off[k], s1 = seg_off[k + 1];
         if (n_chunks[k] == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
-        for (int i = s0; i < s1; ++i) {
+        for (int i = s0; i < s1 && !h_bad[k]; ++i) {   // (a haystack with non-finite scores teaches the threshold nothing)
             if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
             if (!my && (!h->have_min[sm] || h_hdr[i].seg_min < h->min_seg_min[sm])) { h->min_seg_min[sm] = h_hdr[i].seg_min; h->have_min[sm] = true; }
         }
         all.clear();
+        // Non-finite samples (NaN, +-inf; f32 sources only).  The reference transforms every window
+        // on its own (audio_matcher.rs:114-122): a window that holds such a sample gets NaN scores
+        // throughout and yields no peak, every other window is untouched.  Here the sample has
+        // poisoned the whole pair of overlap-save blocks around it, which reaches into neighbouring
+        // chunks.  So, when a score kernel has reported a non-finite score for this haystack: find
+        // the block pairs and the windows that hold such samples; a window that holds one yields
+        // no peak; a clean window whose scores came from a poisoned pair is correlated again on its
+        // own samples (as the reference does it) and picked from that.
+        std::vector<char> drop, again;
+        if (h_bad[k]) {
+            if ((rc = classify_nonfinite(h, o, (const float*)d_hays[k], lens[k], out_count, segs, s0, s1, &drop, &again))) return rc;
+        }
         // collect in window order (audio_matcher.rs:132-133)
         for (int i = s0; i < s1; ++i) {
+            if (!drop.empty() && drop[i - s0]) continue;
+            if (!again.empty() && again[i - s0]) {
+                const Segment sg = segs[i];
+                const long long cnt = sg.b - sg.a;
+                ScanRequest one{};
+                one.theta = -FLT_MAX;
+                PeakArena own{};
+                if ((rc = c->spill.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+                AM_HIP(hipMemsetAsync(c->arena_cur.p, 0, sizeof(unsigned), c->stream));
+                own.base = static_cast<am_peak*>(c->spill.p); own.cursor = static_cast<unsigned*>(c->arena_cur.p);
+                own.cap = AM_MAX_PEAKS_PER_CHUNK;
+                if ((rc = run_correlation(h, o, advance_src(d_hays[k], (size_t)sg.a), (long long)widths[i], 0, (float*)c->scores.p, cnt,
+                                          factor, &one, src_kind))) return rc;
+                if ((rc = launch_pick(c, (const float*)c->scores.p, cnt, local_seg, 1, p->min_prominence,
+                                      (long long)p->min_distance, &one, spare_hdr, own))) return rc;
+                AM_HIP(hipStreamSynchronize(c->stream));
+                const SegHeader& hd = h_hdr[spare_hdr];
+                if (hd.overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
+                const size_t old = all.size();
+                append_header_peaks(hd, own, all);
+                for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }
+                continue;
+            }
             if (!(h_hdr[i].overflow & 6)) { append_header_peaks(h_hdr[i], arena, all); continue; }
             // Rare: theta was too high for this chunk (its minimum lies further below the lowest
             // minimum seen so far than half a prominence), or its list found no room in the spill
@@ -1398,6 +1487,8 @@ int am_shutdown(void) {
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
         if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }
         if (c->spill.p) { (void)hipHostFree(c->spill.p); c->spill.p = nullptr; c->spill.cap = 0; }
+        if (c->badflag.p) { (void)hipHostFree(c->badflag.p); c->badflag.p = nullptr; c->badflag.cap = 0; }
+        c->ranges.release(); c->range_flags.release();
         c->segs_resident.clear();
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
         c->plans.clear();

@@ -84,8 +84,11 @@ bool plan_has_scan(const PlanDev& pl);   // K3 of this plan carries the fused sc
 bool plan_k2_is_r16(const PlanDev& pl);
 hipError_t fft_kernels_init();
 
-hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats);
-hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats);
+// flags[r] = 1 if x[ranges[r].a .. ranges[r].b) holds a non-finite sample (f32 sources only)
+hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment* ranges, int nranges, int* flags);
+// bad (optional, host-visible word): set to 1 when a score is not finite
+hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats, int* bad = nullptr);
+hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats, int* bad = nullptr);
 // per-chunk result header: the count, an overflow flag and the first few peaks
 // inline, so that the common case needs a single small device-to-host copy
 constexpr int kInlinePeaks = 4;

@@ -44,14 +44,20 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, long long n, float2* __restrict__ stats) {
+// `bad` (optional, host-visible): set to 1 when a score is not finite.  A NaN or an infinity among
+// the samples of an overlap-save block poisons every score of the block pair it belongs to (the
+// transforms spread it); fminf / fmaxf drop NaNs, so the summaries would hide them.
+__device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) <= FLT_MAX); }
+__global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, long long n, float2* __restrict__ stats, int* bad) {
     __shared__ float smin[4], smax[4];
     const long long base = (long long)blockIdx.x * kTile;
     float mn = FLT_MAX, mx = -FLT_MAX;
+    bool nf = false;
     for (int i = threadIdx.x; i < kTile; i += 256) {
         const long long idx = base + i;
-        if (idx < n) { const float v = g[idx]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+        if (idx < n) { const float v = g[idx]; mn = fminf(mn, v); mx = fmaxf(mx, v); nf |= not_finite(v); }
     }
+    if (nf && bad != nullptr) *bad = 1;
     mn = wave_min(mn); mx = wave_max(mx);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { smin[wv] = mn; smax[wv] = mx; }
@@ -64,8 +70,10 @@ __global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, l
 
 // level-1 summary (1024 scores) from K3's level-0 summary (32 scores): eight lanes
 // per tile, each with four consecutive entries (two 16-byte loads)
+// (a run of 32 scores that were all NaN has no ordered (min,max) pair; an infinite one shows in it)
+__device__ __forceinline__ bool bad_run(float mn, float mx) { return !(mn <= mx) || not_finite(mn) || not_finite(mx); }
 __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s32, long long n32,
-                                                    float2* __restrict__ stats, long long ntiles) {
+                                                    float2* __restrict__ stats, long long ntiles, int* bad) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long tile = gid >> 3;
     const int l = threadIdx.x & 7;
@@ -77,9 +85,13 @@ __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s
             const float4 b = *reinterpret_cast<const float4*>(s32 + idx + 2);
             mn = fminf(fminf(a.x, a.z), fminf(b.x, b.z));
             mx = fmaxf(fmaxf(a.y, a.w), fmaxf(b.y, b.w));
+            if (bad != nullptr && (bad_run(a.x, a.y) || bad_run(a.z, a.w) || bad_run(b.x, b.y) || bad_run(b.z, b.w))) *bad = 1;
         } else {
             for (int k = 0; k < 4; ++k)
-                if (idx + k < n32) { const float2 v = s32[idx + k]; mn = fminf(mn, v.x); mx = fmaxf(mx, v.y); }
+                if (idx + k < n32) {
+                    const float2 v = s32[idx + k]; mn = fminf(mn, v.x); mx = fmaxf(mx, v.y);
+                    if (bad != nullptr && bad_run(v.x, v.y)) *bad = 1;
+                }
         }
     }
 #pragma unroll
@@ -916,6 +928,16 @@ __global__ void __launch_bounds__(256) pcm_downmix_kernel(const int16_t* __restr
     }
 }
 
+// grid (parts, nranges): does a range of samples hold a NaN or an infinity?
+__global__ void __launch_bounds__(256) nonfinite_ranges_kernel(const float* __restrict__ x, const Segment* __restrict__ ranges,
+                                                               int* __restrict__ flags) {
+    const Segment r = ranges[blockIdx.y];
+    bool found = false;
+    for (long long i = r.a + (long long)blockIdx.x * 256 + threadIdx.x; i < r.b; i += (long long)gridDim.x * 256)
+        found |= !(fabsf(x[i]) <= FLT_MAX);
+    if (found) flags[blockIdx.y] = 1;
+}
+
 static inline int grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -923,19 +945,19 @@ static inline int grid_for(long long n) {
     return (int)b;
 }
 
-hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats) {
+hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats, int* bad) {
     const long long tiles = (n + kTile - 1) / kTile;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_stats, dim3((unsigned)tiles), dim3(256), 0, st, g, n, stats);
+    hipLaunchKernelGGL(tile_stats, dim3((unsigned)tiles), dim3(256), 0, st, g, n, stats, bad);
     return hipGetLastError();
 }
 
-hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats) {
+hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats, int* bad) {
     const long long n32 = (n + 31) / 32;
     const long long tiles = (n + kTile - 1) / kTile;
     if (tiles <= 0) return hipSuccess;
     const long long blocks = (tiles * 8 + 255) / 256;
-    hipLaunchKernelGGL(stats_reduce, dim3((unsigned)blocks), dim3(256), 0, st, stats32, n32, stats, tiles);
+    hipLaunchKernelGGL(stats_reduce, dim3((unsigned)blocks), dim3(256), 0, st, stats32, n32, stats, tiles, bad);
     return hipGetLastError();
 }
 
@@ -953,6 +975,12 @@ hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const f
         hipLaunchKernelGGL(peaks_finish, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs, min_prom, min_dist,
                            d_out, d_hdr, sp, arena, wide);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment* ranges, int nranges, int* flags) {
+    if (nranges <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nonfinite_ranges_kernel, dim3(64, nranges), dim3(256), 0, st, x, ranges, flags);
     return hipGetLastError();
 }
 

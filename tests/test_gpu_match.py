@@ -382,10 +382,10 @@ def test_error_codes(gpu):
 def test_degenerate_signals_terminate(gpu, oracle):
     """Inputs the reference would choke on must not hang or crash the device: a silent
     haystack (every score exactly 0: one plateau, no peak), a silent needle (energy 0:
-    every scaled score is NaN) and a haystack with NaNs / infinities in one place.  Those
-    poison the PAIR of overlap-save blocks that holds them (two blocks share one complex
-    transform), i.e. up to 2 x hop scores, where the reference loses one chunk; hits beyond
-    that pair are still found."""
+    every scaled score is NaN) and a haystack with NaNs / infinities in one place (the windows
+    that hold them lose their peaks, as in the reference; every other hit is still found --
+    tests/test_gpu_round2.py::test_non_finite_samples_cost_only_their_own_windows checks that
+    against the checker window by window)."""
     sr = 44100
     s = 2 * sr
     needle = oracle.synth_uniform(5, 0, 0, s)

@@ -552,3 +552,58 @@ def test_half_pipeline_levels_on_both_plans_and_several_needles(gpu, oracle, lev
         res = gpu.match_multi_device(algos, buf.ptr, hay.size, p)   # (takes the first handle's options)
         for got, ex in zip(res, exps):
             assert_same(got, ex, tol=1e-3)
+
+
+def test_non_finite_samples_cost_only_their_own_windows(gpu, oracle):
+    """A NaN / infinity among the samples: the reference transforms every window on its own
+    (audio_matcher.rs:114-122), so exactly the windows that hold the sample lose their peaks.  The
+    overlap-save blocks here are longer than a window and a bad sample poisons the whole block pair:
+    the library has to notice, drop the windows that hold the sample and correlate the clean windows
+    of that pair again.  Checked against the checker's per-window result on the register plan
+    (8 kHz x 100 s), the generic plan (30 s), a batch with one bad haystack, and the direct-summation
+    path (48-sample needle)."""
+    sr = 8000
+    s = 2 * sr
+    needle = oracle.synth_uniform(5, 0, 0, s)
+    cfg = gpu.Config(chunk_size_s=10.0, overlap_length_s=2.0, distance_s=5.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+
+    def case(secs, plants, bad_at):
+        hay = oracle.synth_uniform(5, 1, 0, secs * sr)
+        for t in plants:
+            hay[t * sr:t * sr + s] += needle
+        bad = hay.copy()
+        for j, v in zip(bad_at, (np.nan, np.inf, -np.inf)):
+            bad[j] = v
+        return hay, bad
+
+    for secs, plants, bad_at in ((100, (13, 35, 57, 81), (34 * sr, 34 * sr + 5)),        # one window lost
+                                 (100, (13, 35, 57, 81), (31 * sr, 31 * sr + 1, 31 * sr + 2)),  # in the overlap: two windows
+                                 (30, (3, 14, 25), (12 * sr + 7,))):                    # generic plan
+        hay, bad = case(secs, plants, bad_at)
+        exp_clean = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+        exp_bad = oracle.calc_chunks(sr, bad, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+        assert len(exp_bad) < len(exp_clean) == len(plants)
+        for _ in range(2):                                   # dense, then sparse score path
+            assert_same(algo.match(bad, p), exp_bad)
+        assert_same(algo.match(hay, p), exp_clean)           # and nothing sticks to the handle
+    # a batch: only the bad haystack takes the slow path
+    hay, bad = case(100, (13, 35, 57, 81), (34 * sr,))
+    exp_clean = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+    exp_bad = oracle.calc_chunks(sr, bad, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+    bufs = [gpu.DeviceBuffer.from_numpy(0, x) for x in (hay, bad, hay)]
+    res = algo.match_batch_device([b.ptr for b in bufs], [hay.size] * 3, p)
+    for got, exp in zip(res, (exp_clean, exp_bad, exp_clean)):
+        assert_same(got, exp)
+    # direct summation (needle of at most 64 samples): a bad sample reaches only s scores, the
+    # reference still loses the whole window
+    tiny = oracle.synth_uniform(6, 0, 0, 48)
+    th = oracle.synth_uniform(6, 1, 0, 40 * sr)
+    for t in (5, 17, 33):
+        th[t * sr:t * sr + 48] += 4.0 * tiny
+    tb = th.copy(); tb[16 * sr] = np.nan
+    pt = gpu.Config(chunk_size_s=10.0, overlap_length_s=1.0, distance_s=5.0, prominence=2.0).params(sr, gpu.Scale.LIB)
+    exp_t = oracle.calc_chunks(sr, tb, tiny, pt.chunk, pt.overlap, 2.0, pt.min_distance, 5.0)
+    assert [e[0] for e in exp_t] == [5 * sr, 33 * sr]
+    assert_same(gpu.HipConvolve(tiny).match(tb, pt), exp_t)
