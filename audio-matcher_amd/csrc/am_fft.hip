@@ -38,6 +38,7 @@
 #include "am_kernels.h"
 
 #include <float.h>
+#include <type_traits>
 #include <hip/hip_fp16.h>
 
 namespace am {
@@ -119,6 +120,37 @@ __device__ __forceinline__ h2 mul_w32(h2 d, int idx) {
     return __builtin_elementwise_fma(d.yx, (h2){s, -s}, t);
 }
 
+// Packed single precision: a complex point as one 64-bit register pair, so that a complex add is
+// one v_pk_add_f32 and a complex multiply one v_pk_mul_f32 + one v_pk_fma_f32 (the swap and the
+// signs ride on op_sel / neg modifiers) -- half the VALU instructions of the scalar form.  Measured,
+// not adopted (AM_K3_PK): a packed instruction takes about 1.75x the issue time of a scalar one.
+typedef float p2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ p2 cadd(p2 a, p2 b) { return a + b; }
+__device__ __forceinline__ p2 csub(p2 a, p2 b) { return a - b; }
+__device__ __forceinline__ p2 cmul(p2 a, p2 b) {
+    const p2 t = a * b.xx;
+    return __builtin_elementwise_fma(a.yx, (p2){-b.y, b.y}, t);
+}
+__device__ __forceinline__ p2 mul_neg_i(p2 a) { return (p2){a.y, -a.x}; }
+__device__ __forceinline__ p2 mul_pos_i(p2 a) { return (p2){-a.y, a.x}; }
+__device__ __forceinline__ p2 to_p2(float2 v) { return (p2){v.x, v.y}; }
+// u + sgn * v (the radix-2 stage of the 512-point column transform)
+__device__ __forceinline__ p2 add_signed(float2 u, float2 v, float sgn, p2) {
+    return __builtin_elementwise_fma(to_p2(v), (p2){sgn, sgn}, to_p2(u));
+}
+__device__ __forceinline__ float2 add_signed(float2 u, float2 v, float sgn, float2) {
+    return make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
+}
+template <bool INV>
+__device__ __forceinline__ p2 mul_w32(p2 d, int idx) {
+    if (idx == 0) return d;
+    if (idx == 8) return INV ? mul_pos_i(d) : mul_neg_i(d);
+    const float c = kCos32[idx], s = kSin32[idx];
+    const p2 t = d * (p2){c, c};
+    if (INV) return __builtin_elementwise_fma(d.yx, (p2){-s, s}, t);
+    return __builtin_elementwise_fma(d.yx, (p2){s, -s}, t);
+}
+
 template <int R, bool INV, typename T>
 __device__ __forceinline__ void dif(T* x) {
     if constexpr (R >= 2) {
@@ -163,6 +195,32 @@ __device__ __forceinline__ void twiddle_apply(h2* x, float2 w) {
         const float2 v = cmul(pw[(e + 1) / 2], pw[e / 2]);
         if (e <= R / 2) pw[e] = v;
         x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], to_h2(v));
+    }
+}
+// packed single precision: powers and products in packed form
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_apply(p2* x, float2 w) {
+    p2 pw[R / 2 + 1];
+    if (CONJ) w.y = -w.y;
+    pw[1] = to_p2(w);
+    x[BREV ? brev<R>(1) : 1] = cmul(x[BREV ? brev<R>(1) : 1], pw[1]);
+#pragma unroll
+    for (int e = 2; e < R; ++e) {
+        const p2 v = cmul(pw[(e + 1) / 2], pw[e / 2]);
+        if (e <= R / 2) pw[e] = v;
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], v);
+    }
+}
+template <int R, bool CONJ, bool BREV>
+__device__ __forceinline__ void twiddle_chain(p2* x, float2 base, float2 step) {
+    if (CONJ) { base.y = -base.y; step.y = -step.y; }
+    p2 c = to_p2(base);
+    const p2 st = to_p2(step);
+    x[0] = cmul(x[0], c);
+#pragma unroll
+    for (int e = 1; e < R; ++e) {
+        c = cmul(c, st);
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], c);
     }
 }
 // two half-precision columns that take the same twiddles (the column passes: the pass twiddle does
@@ -985,10 +1043,10 @@ __device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan,
 // The end of K3 for one column tile: x0 / x1[brev(a)] hold the correlation values of rows
 // n1 = a * 2^HB + hi (columns col, col+1; real part = block A, imaginary part = block B):
 // scaling, fused score scan, block vote, conditional raw-score store.
-template <int HB>
+template <int HB, typename T>
 __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, const K3Edges& ed, float2* lds2,
                                           int n2_0, int out_stride, int t, long long blkA, long long blkB,
-                                          float out_scale, const float2 (&x0)[16], const float2 (&x1)[16]) {
+                                          float out_scale, const T (&x0)[16], const T (&x1)[16]) {
     const int hi = t >> 4, cp = t & 15;
     const long long col = n2_0 + 2 * cp;
     const long long outA = ed.outA, outB = ed.outB, ecA = ed.ecA, edA = ed.edA, ecB = ed.ecB, edB = ed.edB;
@@ -1000,7 +1058,7 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
     float sa0[16], sa1[16], sb0[16], sb1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
-        const float2 v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
+        const T v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
         sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
         sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
     }
@@ -1334,7 +1392,12 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned n2 = (unsigned)n2_0 + 2u * (unsigned)cp;
-    float2 x0[16], x1[16];
+#ifndef AM_K3_PK
+#define AM_K3_PK 0   // 1 = the 512-row K3's butterflies in packed f32: 40 % fewer VALU instructions, the same 0.170 ms
+                     // (tools/pkbench: v_pk_fma_f32 delivers 1.14x the flops of v_fma_f32 at 4 waves per SIMD, not 2x)
+#endif
+    using T = typename std::conditional<AM_K3_PK != 0, p2, float2>::type;
+    T x0[16], x1[16];
     if constexpr (HALF == 2) {
         // first pass (pipeline twiddle, 16-point transform over beta, the W_32 branch factors) and the
         // exchange on packed half-precision points, both columns in one exchange; the second pass and
@@ -1376,8 +1439,8 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
         for (int a2 = 0; a2 < 16; ++a2) {
             const uint2 u = ldsu[c512_idx3(a2, bb, cp)], v = ldsu[c512_idx3(a2, bb + 16, cp)];
             const float2 u0 = to_f2(bits_h2(u.x)), v0 = to_f2(bits_h2(v.x)), u1 = to_f2(bits_h2(u.y)), v1 = to_f2(bits_h2(v.y));
-            x0[a2] = make_float2(fmaf(sgn, v0.x, u0.x), fmaf(sgn, v0.y, u0.y));
-            x1[a2] = make_float2(fmaf(sgn, v1.x, u1.x), fmaf(sgn, v1.y, u1.y));
+            x0[a2] = T{fmaf(sgn, v0.x, u0.x), fmaf(sgn, v0.y, u0.y)};
+            x1[a2] = T{fmaf(sgn, v1.x, u1.x), fmaf(sgn, v1.y, u1.y)};
         }
         twiddle_nat<16, true>(x0, w512);
         twiddle_nat<16, true>(x1, w512);
@@ -1391,16 +1454,17 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
 #pragma unroll
         for (int bt = 0; bt < 16; ++bt) {
             const uint2 v = in2[(size_t)(k10 + 32 * bt) * (kN2 / 2)];
-            x0[bt] = unpack_h2(v.x);
-            x1[bt] = unpack_h2(v.y);
+            const float2 f0 = unpack_h2(v.x), f1 = unpack_h2(v.y);
+            x0[bt] = T{f0.x, f0.y};
+            x1[bt] = T{f1.x, f1.y};
         }
     } else {
         const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
 #pragma unroll
         for (int bt = 0; bt < 16; ++bt) {   // rows k1 = k10 + 32*beta
             const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(k10 + 32 * bt) * (kN2 / 2));
-            x0[bt] = make_float2(v.x, v.y);
-            x1[bt] = make_float2(v.z, v.w);
+            x0[bt] = T{v.x, v.y};
+            x1[bt] = T{v.z, v.w};
         }
     }
     const K3Edges ed = k3_edges(job, scan, blkA, blkB);
@@ -1427,21 +1491,21 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const float sgn = hi >= 16 ? -1.0f : 1.0f;
     const int bb = hi & 15;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = x0[brev<16>(b)];
+    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = make_float2(x0[brev<16>(b)].x, x0[brev<16>(b)].y);
     __syncthreads();
 #pragma unroll
     for (int a2 = 0; a2 < 16; ++a2) {
         const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
-        x0[a2] = make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
+        x0[a2] = add_signed(u, v, sgn, T{});
     }
     __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = x1[brev<16>(b)];
+    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = make_float2(x1[brev<16>(b)].x, x1[brev<16>(b)].y);
     __syncthreads();
 #pragma unroll
     for (int a2 = 0; a2 < 16; ++a2) {
         const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
-        x1[a2] = make_float2(fmaf(sgn, v.x, u.x), fmaf(sgn, v.y, u.y));
+        x1[a2] = add_signed(u, v, sgn, T{});
     }
     twiddle_nat<16, true>(x0, w512);   // conj(W_512^(b*a'))
     twiddle_nat<16, true>(x1, w512);
