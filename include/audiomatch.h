@@ -253,9 +253,12 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *       on a second stream beside the transforms of haystack k+1
  *   "needle_group" (1..8, default 8): how many needles of am_match_multi_device share
  *       one forward row transform of the haystack (1 = one row pass per needle)
- *   "half_pipeline" (0/1): store the transform's work matrix in half precision
- *       (BASELINE config 5).  Butterflies stay f32; scores then carry an absolute
- *       error of about 1e-5 of the chunk's score range, hit offsets are unaffected.
+ *   "half_pipeline" (0/1/2, BASELINE config 5; 0 = off, the default): 1 = the transform's work
+ *       matrix travels through HBM in half precision, butterflies stay f32 (scores within about
+ *       2e-5 on noise-like audio); 2 = the butterflies run in packed f16 as well (the row kernel
+ *       on every plan, the column kernels' f16 forms on the 2^22 plan; scores within about
+ *       4e-4).  Hit offsets are unaffected.  Meant for audio-level signals: full-scale input
+ *       stays inside f16's range, inputs far above full scale may overflow it.
  *   "dense_scores" (0/1): write every raw score from the inverse pass (threshold -inf)
  *       instead of only the tiles that can matter to the peak pick; results are
  *       identical, this is the worst case of the sparse-score path for measurements. */

@@ -15,6 +15,10 @@ done
 python3 tools/pmc_summary.py "$out/pmc" "$out/pmc_traffic.json" > "$out/pmc_summary.log" 2>&1
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
 rm -rf "$out/stats" "$out/pmc"
+for level in 1 2; do
+  python3 bench.py $lean --half-pipeline $level > "$out/bench_half$level.json" 2> "$out/bench_half$level.err" || exit 1
+done
+tools/sq_counters.sh "$out/sq" > /dev/null 2>&1 && cp "$out/sq/sq_counters.json" "$out/sq_counters.json"
 python3 tools/extra_bench.py > "$out/extra.json" 2> "$out/extra.err"
 python3 tools/multi_bench.py 32 8 > "$out/multi32.json" 2> "$out/multi32.err"
 echo collected
