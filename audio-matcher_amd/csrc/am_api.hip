@@ -144,6 +144,7 @@ struct Ctx {
     HostBuf spill;   // spill arena of the single-chunk passes (same kind of memory)
     HostBuf badflag; // one word per haystack of a call: "some score was not finite"
     DevBuf ranges, range_flags;   // work area of the non-finite-sample search (rare path)
+    DevBuf big;                   // lists, sort keys and bucket table of a chunk with more than AM_MAX_PEAKS_PER_CHUNK peaks (rare path)
     // the chunk list currently resident in `segs` (re-uploaded only when it changes)
     std::vector<Segment> segs_resident;
     // profiling
@@ -611,11 +612,68 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     wide.count = reinterpret_cast<unsigned*>(wide.state + nsegs);
     wide.seg_min = reinterpret_cast<float*>(wide.state + 2 * nsegs);
     wide.list = static_cast<am_peak*>(c->wide_list.p);
+    wide.cap = AM_MAX_PEAKS_PER_CHUNK;
     {
         ProfScope ps(c, KN_PEAKS, st);
         AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
                             (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide));
+    }
+    return AM_OK;
+}
+
+// A chunk whose pick reported more than AM_MAX_PEAKS_PER_CHUNK peaks passing the prominence filter
+// (SegHeader::overflow & 1): find_peaks returns them all, so does this path.  The scores, their
+// tile summary (set 0) and the resident chunk `seg_idx` are those of the pick that just failed.
+// Count the qualifying peaks, build the list in global memory, sort and filter it on the device
+// (am_peaks.hip, peaks_big_finish), fetch the survivors.  Synchronous; appends to `all`.
+static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int seg_idx, const Segment& sg,
+                          float min_prom, long long min_dist, const ScanRequest* scan, float seg_min,
+                          std::vector<am_peak>& all) {
+    const long long a = sg.a, b = std::min(sg.b, n_scores);
+    if (b - a >= 0xFFFFFFFFll) return fail(AM_ERR_PEAK_OVERFLOW, "chunk of 2^32 scores or more with more than AM_MAX_PEAKS_PER_CHUNK peaks");
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
+    int rc;
+    if ((rc = c->wide_ctl.ensure(24))) return rc;
+    struct Ctl { unsigned long long best; int state; unsigned count; float seg_min; unsigned pad; } ctl{0ull, 1, 0u, seg_min, 0u};
+    WideState wide{};
+    wide.best = static_cast<unsigned long long*>(c->wide_ctl.p);
+    wide.state = reinterpret_cast<int*>(wide.best + 1);
+    wide.count = reinterpret_cast<unsigned*>(wide.state + 1);
+    wide.seg_min = reinterpret_cast<float*>(wide.state + 2);
+    const Segment* d_seg = (const Segment*)c->segs.p + seg_idx;
+    // pass 1: count
+    wide.list = nullptr; wide.cap = 0;
+    AM_HIP(hipMemcpyAsync(c->wide_ctl.p, &ctl, 24, hipMemcpyHostToDevice, c->stream));
+    AM_HIP(launch_peaks_wide_one(c->stream, d_scores, n_scores, (const float2*)c->stats.p, d_seg, min_prom, min_dist, sp, wide));
+    unsigned n = 0;
+    AM_HIP(hipMemcpyAsync(&n, wide.count, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    if (n == 0) return AM_OK;
+    if (n >= 0x40000000u) return fail(AM_ERR_PEAK_OVERFLOW, "peak list build failed");
+    // one allocation: list | out | keys (2n) | table | idx (2n) | out_n
+    const size_t nb = min_dist > 0 ? (size_t)((b - a) / min_dist) + 3 : 1;
+    const size_t off_out = sizeof(am_peak) * (size_t)n, off_keys = 2 * off_out, off_table = off_keys + 16 * (size_t)n,
+                 off_idx = off_table + 8 * nb, off_n = off_idx + 8 * (size_t)n;
+    if ((rc = c->big.ensure(off_n + 16))) return rc;
+    char* base = static_cast<char*>(c->big.p);
+    // pass 2: fill the list (in any order)
+    wide.list = reinterpret_cast<am_peak*>(base); wide.cap = n;
+    AM_HIP(hipMemcpyAsync(c->wide_ctl.p, &ctl, 24, hipMemcpyHostToDevice, c->stream));
+    AM_HIP(launch_peaks_wide_one(c->stream, d_scores, n_scores, (const float2*)c->stats.p, d_seg, min_prom, min_dist, sp, wide));
+    AM_HIP(hipMemsetAsync(base + off_table, 0xFF, 8 * nb, c->stream));
+    AM_HIP(launch_peaks_big_finish(c->stream, wide.list, n, a, min_dist, reinterpret_cast<unsigned long long*>(base + off_keys),
+                                   reinterpret_cast<unsigned*>(base + off_idx), reinterpret_cast<long long*>(base + off_table),
+                                   reinterpret_cast<am_peak*>(base + off_out), reinterpret_cast<unsigned*>(base + off_n)));
+    unsigned kept = 0;
+    AM_HIP(hipMemcpyAsync(&kept, base + off_n, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    if (kept > n) return fail(AM_ERR_PEAK_OVERFLOW, "peak filter failed");
+    const size_t old = all.size();
+    all.resize(old + kept);
+    if (kept) {
+        AM_HIP(hipMemcpyAsync(all.data() + old, base + off_out, sizeof(am_peak) * (size_t)kept, hipMemcpyDeviceToHost, c->stream));
+        AM_HIP(hipStreamSynchronize(c->stream));
     }
     return AM_OK;
 }
@@ -851,7 +909,6 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         if (n_chunks[k] == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
         for (int i = s0; i < s1 && !h_bad[k]; ++i) {   // (a haystack with non-finite scores teaches the threshold nothing)
-            if (h_hdr[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
             if (!my && (!h->have_min[sm] || h_hdr[i].seg_min < h->min_seg_min[sm])) { h->min_seg_min[sm] = h_hdr[i].seg_min; h->have_min[sm] = true; }
         }
         all.clear();
@@ -886,16 +943,19 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                                       (long long)p->min_distance, &one, spare_hdr, own))) return rc;
                 AM_HIP(hipStreamSynchronize(c->stream));
                 const SegHeader& hd = h_hdr[spare_hdr];
-                if (hd.overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
                 const size_t old = all.size();
-                append_header_peaks(hd, own, all);
+                if (hd.overflow & 1) {
+                    if ((rc = pick_chunk_big(c, (const float*)c->scores.p, cnt, local_seg, Segment{0, cnt}, p->min_prominence,
+                                             (long long)p->min_distance, &one, hd.seg_min, all))) return rc;
+                } else append_header_peaks(hd, own, all);
                 for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }
                 continue;
             }
-            if (!(h_hdr[i].overflow & 6)) { append_header_peaks(h_hdr[i], arena, all); continue; }
+            if (!(h_hdr[i].overflow & 7)) { append_header_peaks(h_hdr[i], arena, all); continue; }
             // Rare: theta was too high for this chunk (its minimum lies further below the lowest
-            // minimum seen so far than half a prominence), or its list found no room in the spill
-            // arena.  Redo the blocks that produce this chunk's scores with theta = -inf, in place
+            // minimum seen so far than half a prominence), its list found no room in the spill
+            // arena, or more than AM_MAX_PEAKS_PER_CHUNK peaks passed the prominence filter (the
+            // score buffers have moved on to later haystacks by now).  Redo the blocks that produce this chunk's scores with theta = -inf, in place
             // in set 0 (same block layout, hence bit-identical scores), and pick the chunk again
             // with a spill arena of its own.
             ScanRequest full = scan;
@@ -912,9 +972,11 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                                   (long long)p->min_distance, &full, spare_hdr, own))) return rc;
             AM_HIP(hipStreamSynchronize(c->stream));
             const SegHeader& hd = h_hdr[spare_hdr];
-            if (hd.overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
             if (!my && hd.seg_min < h->min_seg_min[sm]) h->min_seg_min[sm] = hd.seg_min;
-            append_header_peaks(hd, own, all);
+            if (hd.overflow & 1) {
+                if ((rc = pick_chunk_big(c, (const float*)c->scores.p, out_count, i, segs[i], p->min_prominence,
+                                         (long long)p->min_distance, &full, hd.seg_min, all))) return rc;
+            } else append_header_peaks(hd, own, all);
         }
         // second pass (MyConvolve scaling only): the shorter windows at the end of the haystack
         for (int i = tail_off[k]; i < tail_off[k + 1]; ++i) {
@@ -935,9 +997,11 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                                   (long long)p->min_distance, &one, spare_hdr, own))) return rc;
             AM_HIP(hipStreamSynchronize(c->stream));
             const SegHeader& hd = h_hdr[spare_hdr];
-            if (hd.overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
             const size_t old = all.size();
-            append_header_peaks(hd, own, all);
+            if (hd.overflow & 1) {
+                if ((rc = pick_chunk_big(c, (const float*)c->scores.p, cnt, (int)nsegs + i, Segment{0, cnt}, p->min_prominence,
+                                         (long long)p->min_distance, &one, hd.seg_min, all))) return rc;
+            } else append_header_peaks(hd, own, all);
             for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }   // audio_matcher.rs:126
         }
         rc = merge_peaks(all, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
@@ -1048,8 +1112,7 @@ static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, 
         const SegHeader* hd = h_hdr + k * nsegs;
         bool redo = false;
         for (int i = 0; i < nsegs; ++i) {
-            if (hd[i].overflow & 1) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
-            if (hd[i].overflow & 6) redo = true;
+            if (hd[i].overflow & 7) redo = true;   // (bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks -- the single-needle path lists them all)
             if (!h->have_min[sm] || hd[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = hd[i].seg_min; h->have_min[sm] = true; }
         }
         all.clear();
@@ -1088,8 +1151,8 @@ static int find_peaks_host_array(Ctx* c, const float* d_scores, long long n, flo
     if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr, 0, arena))) return rc;
     AM_HIP(hipStreamSynchronize(c->stream));
     const SegHeader hd = *static_cast<const SegHeader*>(c->hdr.p);
-    if (hd.overflow) return fail(AM_ERR_PEAK_OVERFLOW, "more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk");
     all.clear();
+    if (hd.overflow) return pick_chunk_big(c, d_scores, n, 0, sg, min_prom, min_dist, nullptr, hd.seg_min, all);
     append_header_peaks(hd, arena, all);
     return AM_OK;
 }
@@ -1488,7 +1551,7 @@ int am_shutdown(void) {
         if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }
         if (c->spill.p) { (void)hipHostFree(c->spill.p); c->spill.p = nullptr; c->spill.cap = 0; }
         if (c->badflag.p) { (void)hipHostFree(c->badflag.p); c->badflag.p = nullptr; c->badflag.cap = 0; }
-        c->ranges.release(); c->range_flags.release();
+        c->ranges.release(); c->range_flags.release(); c->big.release();
         c->segs_resident.clear();
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
         c->plans.clear();

@@ -125,7 +125,19 @@ struct WideState {
     float* seg_min;
     unsigned long long* best;   // min_distance >= chunk length: running maximum of the peaks that pass (order-preserving key)
     am_peak* list;
+    unsigned cap;        // entries per chunk in list (AM_MAX_PEAKS_PER_CHUNK on the usual path)
 };
+// A chunk with more than AM_MAX_PEAKS_PER_CHUNK peaks passing the prominence filter (rare: a
+// min_distance shorter than the chunk and a tiny prominence bound).  launch_peaks_wide_one runs the
+// list-building kernel for ONE chunk (wide.state[0] must be 1; wide.cap = 0 only counts);
+// launch_peaks_big_finish orders that list by (height descending, position ascending) with a
+// radix sort in global memory and applies the greedy min_distance filter through a table of
+// min_distance-wide buckets (each holds at most one kept peak).  Scratch: keys 2 x n x 8 bytes,
+// idx 2 x n x 4 bytes, table ((b - a) / min_distance + 3) x 8 bytes preset to 0xFF.
+hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len, const float2* stats, const Segment* d_seg,
+                                 float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide);
+hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
+                                   unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n);
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,

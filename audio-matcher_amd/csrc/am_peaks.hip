@@ -565,7 +565,7 @@ __device__ void finish_chunk(am_peak* res, int rn, int* order, int overflow, lon
 // preserving key is enough, and nothing can overflow.  The winner's plateau end and prominence
 // are worked out again at the end (one scan, one walk).
 __device__ __forceinline__ unsigned long long best_key(float h, long long rel) {
-    unsigned u = __float_as_uint(h);
+    unsigned u = __float_as_uint(h + 0.0f);   // (-0.0 and +0.0 are the same height: one key)
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)rel);
 }
@@ -578,8 +578,11 @@ __device__ void finish_best(const ChunkView& cv, unsigned long long key, am_peak
     }
     unsigned u = (unsigned)(key >> 32);
     u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-    const float h = __uint_as_float(u);
     const long long ps = cv.a + (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    // the height as the score array holds it (the key does not tell -0.0 from +0.0); a peak that
+    // passed the prominence filter lies in a written tile
+    const float hk = __uint_as_float(u), hs = score_for_cmp(cv.g, cv.sp, ps);
+    const float h = hs == hk ? hs : hk;
     if (tid == 0) {
         long long k = ps + 1;
         while (k < cv.b - 1 && score_for_cmp(cv.g, cv.sp, k) == h) ++k;
@@ -825,12 +828,12 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
     if (tid == 0) { queue_n = 0; overflow = 0; }
     __syncthreads();
     ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
-    am_peak* list = wide.list + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
+    am_peak* list = wide.list + (size_t)seg * wide.cap;
     const bool best_mode = min_dist >= b - a && b - a < 0xFFFFFFFFll;
     auto emit = [&](long long ps, long long pe, float h, float prom) {
         if (best_mode) { atomicMax(&wide.best[seg], best_key(h, ps - a)); return; }
         const unsigned slot = atomicAdd(&wide.count[seg], 1u);
-        if (slot < (unsigned)AM_MAX_PEAKS_PER_CHUNK) {
+        if (slot < wide.cap) {
             am_peak pk; pk.start = (uint64_t)ps; pk.end = (uint64_t)pe; pk.height = h; pk.prominence = prom;
             list[slot] = pk;
         }
@@ -844,7 +847,104 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
             if (!((stats[t].y - seg_min) >= min_prom)) continue;
             scan_piece(cv, t * kTile, (t + 1) * kTile, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
         }
-    if (tid == 0 && overflow) atomicAdd(&wide.count[seg], (unsigned)AM_MAX_PEAKS_PER_CHUNK + 1u);   // poisons the count: reported as overflow
+    if (tid == 0 && overflow) atomicAdd(&wide.count[seg], 0x40000000u);   // (cannot happen, see kWideQueue) poisons the count
+}
+
+// ---------------------------------------------------------------------------
+// More than AM_MAX_PEAKS_PER_CHUNK peaks pass the prominence filter in one chunk: the list lives in
+// global memory (built by peaks_wide with a capacity of its own) and ONE workgroup finishes it.
+// (1) keys: height descending, position ascending, as one order-preserving 64-bit key (best_key).
+// (2) a stable LSD radix sort, 4 bits per pass, descending: every thread owns a contiguous slice,
+//     counts its digits into its own LDS column, a block scan turns the counts into offsets, the
+//     thread scatters its slice in order.  16 passes, ping-pong between the two halves of keys / idx.
+// (3) the greedy filter (finish_chunk's rule: keep a peak unless a kept one lies closer than
+//     min_dist between plateau centres), one wavefront, 64 peaks per step in priority order: kept
+//     peaks are entered into a table of min_dist-wide buckets by centre -- two kept centres are at
+//     least min_dist apart, so a bucket holds at most one, and a conflict can only sit in the
+//     peak's own bucket or a neighbouring one; conflicts inside the step are settled lane by lane.
+constexpr int kBigThreads = 256;
+__global__ void __launch_bounds__(kBigThreads)
+peaks_big_finish(const am_peak* __restrict__ list, unsigned n, long long a, long long min_dist,
+                 unsigned long long* keys, unsigned* idx, long long* table, am_peak* __restrict__ out, unsigned* out_n) {
+    __shared__ unsigned cnt[16 * kBigThreads];
+    __shared__ unsigned part[kBigThreads];
+    const int tid = threadIdx.x;
+    unsigned long long* k0 = keys; unsigned long long* k1 = keys + n;
+    unsigned* i0 = idx; unsigned* i1 = idx + n;
+    for (unsigned i = tid; i < n; i += kBigThreads) { k0[i] = best_key(list[i].height, (long long)list[i].start - a); i0[i] = i; }
+    const unsigned per = (n + kBigThreads - 1) / kBigThreads;
+    const unsigned lo = (unsigned)tid * per < n ? (unsigned)tid * per : n;
+    const unsigned hi = lo + per < n ? lo + per : n;
+    for (int pass = 0; pass < 16; ++pass) {
+        __syncthreads();   // the previous pass's (or the key loop's) global stores are visible to the workgroup
+        const unsigned long long* kin = (pass & 1) ? k1 : k0;
+        unsigned long long* kout = (pass & 1) ? k0 : k1;
+        const unsigned* iin = (pass & 1) ? i1 : i0;
+        unsigned* iout = (pass & 1) ? i0 : i1;
+        const int sh = 4 * pass;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d * kBigThreads + tid] = 0;
+        for (unsigned i = lo; i < hi; ++i) ++cnt[(15 - (int)((kin[i] >> sh) & 15ull)) * kBigThreads + tid];
+        __syncthreads();
+        // exclusive scan of the 4096 counts in (digit, thread) order: 16 consecutive entries per thread
+        unsigned sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += cnt[tid * 16 + j];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid == 0) { unsigned run = 0; for (int t = 0; t < kBigThreads; ++t) { const unsigned v = part[t]; part[t] = run; run += v; } }
+        __syncthreads();
+        unsigned run = part[tid];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const unsigned v = cnt[tid * 16 + j]; cnt[tid * 16 + j] = run; run += v; }
+        __syncthreads();
+        for (unsigned i = lo; i < hi; ++i) {
+            const unsigned long long k = kin[i];
+            const unsigned pos = cnt[(15 - (int)((k >> sh) & 15ull)) * kBigThreads + tid]++;
+            kout[pos] = k; iout[pos] = iin[i];
+        }
+    }
+    __syncthreads();   // 16 passes: the sorted order is back in the first halves
+    if (tid >= 64) return;
+    const int lane = tid;
+    unsigned kept = 0;
+    for (unsigned base = 0; base < n; base += 64) {
+        const unsigned i = base + lane;
+        bool ok = i < n;
+        am_peak pk; pk.start = 0; pk.end = 0; pk.height = 0.f; pk.prominence = 0.f;
+        long long mid = 0, bkt = 0;
+        if (ok) {
+            pk = list[i0[i]];
+            mid = (long long)((pk.start + pk.end) / 2) - a;
+            if (min_dist > 0) {
+                bkt = mid / min_dist;
+                for (long long bb = bkt > 0 ? bkt - 1 : 0; bb <= bkt + 1 && ok; ++bb) {
+                    const long long m = __hip_atomic_load(&table[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (m >= 0) { const long long d = mid > m ? mid - m : m - mid; if (d < min_dist) ok = false; }
+                }
+            }
+        }
+        bool keep = ok;
+        if (min_dist > 0) {
+            keep = false;
+            unsigned long long pending = __ballot(ok);
+            while (pending) {
+                const int L = __ffsll((long long)pending) - 1;
+                const long long midL = ((long long)__shfl((int)(mid >> 32), L) << 32) | (unsigned)__shfl((int)(mid & 0xffffffffll), L);
+                if (lane == L) keep = true;
+                if (ok && lane > L) { const long long d = mid > midL ? mid - midL : midL - mid; if (d < min_dist) ok = false; }
+                pending = __ballot(ok && lane > L);
+            }
+        }
+        const unsigned long long kb = __ballot(keep);
+        if (keep) {
+            out[kept + (unsigned)__popcll(kb & ((1ull << lane) - 1ull))] = pk;
+            if (min_dist > 0) __hip_atomic_store(&table[bkt], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        kept += (unsigned)__popcll(kb);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // this step's table entries before the next step's look-ups
+    }
+    if (lane == 0) *out_n = kept;
 }
 
 // grid nsegs: sort + distance filter of a chunk that went through peaks_wide
@@ -981,6 +1081,17 @@ hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const f
 hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment* ranges, int nranges, int* flags) {
     if (nranges <= 0) return hipSuccess;
     hipLaunchKernelGGL(nonfinite_ranges_kernel, dim3(64, nranges), dim3(256), 0, st, x, ranges, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len, const float2* stats, const Segment* d_seg,
+                                 float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide) {
+    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, min_prom, min_dist, sp, wide);
+    return hipGetLastError();
+}
+hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
+                                   unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n) {
+    hipLaunchKernelGGL(peaks_big_finish, dim3(1), dim3(kBigThreads), 0, st, list, n, a, min_dist, keys, idx, table, out, out_n);
     return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@ enum {
     AM_ERR_CAPACITY = 2,      /* caller buffer too small; required length was written */
     AM_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed */
     AM_ERR_NO_DEVICE = 4,     /* no gfx950-capable device / bad ordinal */
-    AM_ERR_PEAK_OVERFLOW = 5, /* more than AM_MAX_PEAKS_PER_CHUNK peaks in one chunk (see there) */
+    AM_ERR_PEAK_OVERFLOW = 5, /* a chunk of 2^32 scores or more with more than AM_MAX_PEAKS_PER_CHUNK peaks */
     AM_ERR_OOM = 6            /* host or device allocation failed */
 };
 
@@ -49,9 +49,11 @@ enum { AM_MODE_FULL = 0, AM_MODE_SAME = 1, AM_MODE_VALID = 2 };
  *                                                  audio_matcher.rs:442-448 */
 enum { AM_SCALE_NONE = 0, AM_SCALE_LIB = 1, AM_SCALE_MY = 2 };
 
-/* Upper bound on peaks that pass the prominence filter inside ONE chunk when min_distance is
- * shorter than the chunk (with min_distance >= chunk length, the reference's default, the
- * distance filter keeps the tallest of however many pass and no bound applies). */
+/* Not a limit on results: any number of peaks may pass the prominence filter in a chunk and, as
+ * find_peaks does, the library returns every one the distance filter keeps (the caller's `cap`
+ * is the only bound).  Up to this many per chunk are ordered and filtered on chip; a chunk with
+ * more (a min_distance shorter than the chunk and a tiny prominence bound) takes a slower path
+ * through a list in device memory. */
 #define AM_MAX_PEAKS_PER_CHUNK 1024
 
 /* Opaque handle = the reference's `LibConvolve { sample_data, .. }` /

@@ -30,12 +30,9 @@ def test_matches_oracle_bit_exact(gpu, oracle, n, seed, min_prom):
     y = np.round(y * 4) / 4  # coarse grid -> many flat tops and ties
     y = y.astype(np.float32)
     exp = oracle.find_peaks(y, min_prom, 0, cap=n)
-    if len(exp) > gpu.AM_MAX_PEAKS_PER_CHUNK:
-        with pytest.raises(gpu.AudioMatchError) as ei:
-            gpu.find_peaks(y, min_prom)
-        assert ei.value.code == gpu.AM_ERR_PEAK_OVERFLOW
-        return
-    got = as_tuples(gpu.find_peaks(y, min_prom))
+    # (lists longer than AM_MAX_PEAKS_PER_CHUNK -- up to 56 000 peaks here -- take the global-memory
+    # sort of peaks_big_finish; find_peaks returns them all, so does the library)
+    got = as_tuples(gpu.find_peaks(y, min_prom, cap=n))
     assert got == exp
 
 

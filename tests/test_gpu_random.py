@@ -76,19 +76,7 @@ def test_find_peaks_random_vs_oracle(gpu, oracle):
         prom = float(rng.choice([0.0, 0.5, 2.0, 8.0]))
         dist = int(rng.choice([0, 1, 7, 500, 50_000]))
         exp = oracle.find_peaks(y, prom, dist, cap=max(16, n))
-        if len(exp) > gpu.AM_MAX_PEAKS_PER_CHUNK:
-            # the documented limit applies to peaks that pass the prominence filter
-            pre = oracle.find_peaks(y, prom, 0, cap=max(16, n))
-            if len(pre) > gpu.AM_MAX_PEAKS_PER_CHUNK:
-                with pytest.raises(gpu.AudioMatchError):
-                    gpu.find_peaks(y, prom, dist)
-                continue
-        pre = oracle.find_peaks(y, prom, 0, cap=max(16, n))
-        if len(pre) > gpu.AM_MAX_PEAKS_PER_CHUNK:
-            with pytest.raises(gpu.AudioMatchError):
-                gpu.find_peaks(y, prom, dist)
-            continue
-        got = [(p.start, p.end, p.height, p.prominence) for p in gpu.find_peaks(y, prom, dist)]
+        got = [(p.start, p.end, p.height, p.prominence) for p in gpu.find_peaks(y, prom, dist, cap=max(16, n))]
         assert got == exp, (trial, n, prom, dist)
 
 

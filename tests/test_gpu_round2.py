@@ -451,6 +451,51 @@ def test_many_qualifying_maxima_small_distance(gpu, oracle):
             assert_same(got, exp)
 
 
+def test_more_than_1024_qualifying_maxima_per_chunk(gpu, oracle):
+    """More peaks pass the prominence filter in one chunk than a workgroup can list in LDS
+    (AM_MAX_PEAKS_PER_CHUNK = 1024): find_peaks returns them all (audio_matcher.rs:221-230), so the
+    chunk goes through the global-memory list, the radix sort by (height, position) and the
+    bucketed greedy distance filter -- with no distance (every one of them comes back), a short one
+    and a long one; single calls (dense, then sparse scores), a batch of two (the score buffers have
+    moved on when the overflow is noticed: the chunk's blocks are redone) and MyConvolve scaling
+    with its separately correlated tail windows."""
+    sr = 8000
+    needle, hay, plants = drifting_case(oracle, sr, 37)
+    algo = gpu.HipConvolve(needle)
+    # With nearly twenty thousand peaks some prominence always lies within rounding of any bound
+    # (0.02 itself has one 4e-8 above it).  Take a bound that the checker's values clear by 2e-6 on
+    # both sides, so that the comparison does not hinge on the last bit of a score.
+    c40 = gpu.Config(chunk_size_s=40.0, overlap_length_s=2.0, distance_s=0.0, prominence=0.02).params(sr, gpu.Scale.LIB)
+    thr = None
+    for k in range(60):
+        cand = 0.02 + 1e-4 * k
+        near = oracle.calc_chunks(sr, hay, needle, c40.chunk, c40.overlap, cand - 2e-6, 0, 0.0, cap=1 << 20)
+        if not any(abs(e[3] - cand) <= 2e-6 for e in near):
+            thr = cand
+            break
+    assert thr is not None
+    for chunk_s, dist_s, prom in ((40.0, 0.0, thr), (40.0, 0.01, thr), (40.0, 2.5, thr)):
+        cfg = gpu.Config(chunk_size_s=chunk_s, overlap_length_s=2.0, distance_s=dist_s, prominence=prom)
+        p = cfg.params(sr, gpu.Scale.LIB)
+        per_chunk = oracle.find_peaks(oracle.correlate(hay[:p.chunk + p.overlap], needle, oracle.MODE_VALID, oracle.SCALE_LIB),
+                                      prom, 0, cap=1 << 20)
+        assert len(per_chunk) > 1100, len(per_chunk)
+        exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, prom, p.min_distance, dist_s, cap=1 << 20)
+        assert len(exp) > 30
+        for _ in range(2):
+            assert_same(algo.match(hay, p, cap=1 << 20), exp)
+    bufs = [gpu.DeviceBuffer.from_numpy(0, hay), gpu.DeviceBuffer.from_numpy(0, hay[: hay.size // 2])]
+    exp2 = oracle.calc_chunks(sr, hay[: hay.size // 2], needle, p.chunk, p.overlap, prom, p.min_distance, dist_s, cap=1 << 20)
+    res = algo.match_batch_device([b.ptr for b in bufs], [hay.size, hay.size // 2], p, cap_per_hay=1 << 16)
+    assert_same(res[0], exp)
+    assert_same(res[1], exp2)
+    pm = cfg.params(sr, gpu.Scale.MY)
+    expm = oracle.calc_chunks(sr, hay, needle, pm.chunk, pm.overlap, prom / (pm.chunk + pm.overlap), pm.min_distance, dist_s,
+                              cap=1 << 20, scale=oracle.SCALE_MY)
+    pm.min_prominence = prom / (pm.chunk + pm.overlap)
+    assert_same(algo.match(hay, pm, cap=1 << 20), expm, tol=1e-8)
+
+
 def test_default_distance_with_thousands_of_qualifying_maxima(gpu, oracle):
     """min_distance >= chunk (the reference's default regime) on a score array whose ripple is
     larger than min_prominence: about two thousand maxima per chunk pass the prominence filter --
