@@ -18,6 +18,9 @@ rm -rf "$out/stats" "$out/pmc"
 for level in 1 2; do
   python3 bench.py $lean --half-pipeline $level > "$out/bench_half$level.json" 2> "$out/bench_half$level.err" || exit 1
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_h2" -o run -- python3 bench.py $lean --half-pipeline 2 > "$out/stats_h2.log" 2>&1 || exit 1
+find "$out/stats_h2" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats_half_level2.csv" \;
+rm -rf "$out/stats_h2"
 tools/sq_counters.sh "$out/sq" > /dev/null 2>&1 && cp "$out/sq/sq_counters.json" "$out/sq_counters.json"
 python3 tools/extra_bench.py > "$out/extra.json" 2> "$out/extra.err"
 python3 tools/multi_bench.py 32 8 > "$out/multi32.json" 2> "$out/multi32.err"
