@@ -497,6 +497,19 @@ def side_measurements(am, device, algo, needle, params, hays, s, h, steps):
                      "note": ("option half_pipeline=1: work matrix stored as f16, f32 butterflies" if level == 1 else
                               "option half_pipeline=2: f16 work matrix and packed-f16 butterflies (K2; K1 and K3's first pass on the 2^22 plan)")}
         halg.close()
+    # (1c) BASELINE configs[0] on the GPU: the one-chunk case the reference's own bench runs on the CPU
+    # (10 s needle vs one 60 s haystack, plant at 20 s), resident, single calls -- latency, not throughput
+    h0 = CHUNK_S * SR
+    small = am.DeviceBuffer(device, 4 * h0)
+    am._check(am.lib().am_synth_uniform_device(device, small.ptr, 1, 1, 0, h0, 0.25))
+    am.axpy_device(device, small, 20 * SR, needle.ptr, s, 1.0)
+    r0 = algo.match_device(small.ptr, h0, params)
+    t = timed(lambda: algo.match_device(small.ptr, h0, params), 50)
+    out["config0_60s_haystack_gpu"] = {"value": h0 / t, "unit": "samples/s", "ms_per_call": t * 1e3,
+                                       "offsets_ok": [p.start for p in r0] == [20 * SR],
+                                       "note": "configs[0] shape on the GPU (cpu_baseline_config1 is its CPU row): one 60 s haystack, "
+                                               "one window, one block pair; a single synchronous call"}
+    small.free()
     # (2) a signal whose scores are not white: slow drift + 440 Hz ripple (see make_tonal)
     tone_needle, tone_algo, tone_hay, plants = make_tonal(am, device, s, h)
     res = tone_algo.match_device(tone_hay.ptr, h, params)
