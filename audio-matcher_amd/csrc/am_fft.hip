@@ -475,7 +475,28 @@ __device__ __forceinline__ void k1_tile(const Job& job, const PlanDev& pl, float
     k1_transform(w, lds2, hi, cp, x0, x1);
 }
 
-template <int KIND, bool HALF>
+// 256-point column FFT + pipeline twiddle on packed half-precision points (option half_pipeline = 2):
+// k1_transform's steps, both columns of the pair through LDS in one exchange
+__device__ __forceinline__ void k1_transform_h16(const K1Twiddles& w, uint2* ldsu, int hi, int cp, h2 (&x0)[16], h2 (&x1)[16]) {
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    twiddle_apply2<16, false, true>(x0, x1, w.w256);
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) ldsu[(ap * 16 + hi) * 17 + cp] = make_uint2(h2_bits(x0[brev<16>(ap)]), h2_bits(x1[brev<16>(ap)]));
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const uint2 v = ldsu[(hi * 16 + b) * 17 + cp];
+        x0[b] = bits_h2(v.x);
+        x1[b] = bits_h2(v.y);
+    }
+    dif<16, false>(x0);
+    dif<16, false>(x1);
+    twiddle_chain<16, false, true>(x0, w.base0, w.step0);
+    twiddle_chain<16, false, true>(x1, w.base1, w.step1);
+}
+
+template <int KIND, int HALF>   // HALF: 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and f16 butterflies
 __global__ void __launch_bounds__(256, 3)
 k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
@@ -491,6 +512,22 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
     const bool fast = ((reinterpret_cast<uintptr_t>(job.src) & 7) == 0) && ((baseA & 1) == 0) && ((baseB & 1) == 0) &&
                       baseA >= 0 && baseA + N <= job.src_len && validB && baseB + N <= job.src_len;
     float2 x0[16], x1[16];
+    if constexpr (HALF == 2) {
+        const long long col = (long long)n2_0 + 2 * cp;
+        const K1Twiddles w = k1_twiddles(pl, col, hi);
+        k1_load<KIND>(job, col, kN2, hi, baseA, baseB, validB, fast, x0, x1);
+        h2 hx0[16], hx1[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) { hx0[a] = to_h2(x0[a]); hx1[a] = to_h2(x1[a]); }
+        k1_transform_h16(w, reinterpret_cast<uint2*>(lds4), hi, cp, hx0, hx1);
+        uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
+#pragma unroll
+        for (int bp = 0; bp < 16; ++bp) {
+            const size_t k1 = (size_t)(hi + 16 * bp);
+            out2[k1 * (kN2 / 2)] = make_uint2(h2_bits(hx0[brev<16>(bp)]), h2_bits(hx1[brev<16>(bp)]));
+        }
+        return;
+    }
     k1_tile<KIND>(job, pl, reinterpret_cast<float2*>(lds4), (long long)n2_0 + 2 * cp, kN2, hi, cp, baseA, baseB, validB, fast, x0, x1);
     if (HALF) {
         uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
@@ -1188,10 +1225,51 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     k3_finish<4>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
 }
 
+// The same with the first pass (pipeline twiddle, 16-point transform over b') and the exchange on
+// packed half-precision points (option half_pipeline = 2): both columns of the pair cross LDS in one
+// exchange; the second pass and everything behind it stay f32, so that no score is rounded to f16.
+__device__ __forceinline__ void k3_tile_h16(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2,
+                                            int n2_0, int out_stride, int t, long long blkA, long long blkB,
+                                            float out_scale, h2 (&hx0)[16], h2 (&hx1)[16]) {
+    const int hi = t >> 4, cp = t & 15;
+    const long long N = 1ll << pl.logN;
+    const long long col = n2_0 + 2 * cp;
+    const K3Edges ed = k3_edges(job, scan, blkA, blkB);
+    const unsigned maskN = (unsigned)(N - 1);
+    const float2 w256 = pl.tw1[hi];
+    {
+        const unsigned n2 = (unsigned)col;
+        const float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
+        const float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
+        const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
+        const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
+        twiddle_chain<16, true, false>(hx0, base0, step0);
+        twiddle_chain<16, true, false>(hx1, base1, step1);
+    }
+    dif<16, true>(hx0);
+    dif<16, true>(hx1);
+    uint2* ldsu = reinterpret_cast<uint2*>(lds2);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) ldsu[(hi * 16 + b) * 16 + cp] = make_uint2(h2_bits(hx0[brev<16>(b)]), h2_bits(hx1[brev<16>(b)]));
+    __syncthreads();
+    float2 x0[16], x1[16];
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) {
+        const uint2 v = ldsu[(ap * 16 + hi) * 16 + cp];
+        x0[ap] = to_f2(bits_h2(v.x));
+        x1[ap] = to_f2(bits_h2(v.y));
+    }
+    twiddle_nat<16, true>(x0, w256);
+    twiddle_nat<16, true>(x1, w256);
+    dif<16, true>(x0);
+    dif<16, true>(x1);
+    k3_finish<4>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
+}
+
 #ifndef AM_K3_WGS
 #define AM_K3_WGS 3   // minimum workgroups per CU the register allocation has to allow (it uses 118 VGPRs: four fit)
 #endif
-template <bool HALF>
+template <int HALF>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
 __global__ void __launch_bounds__(256, AM_K3_WGS)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1205,6 +1283,18 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     const int n2_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
     const long long blkA = 2ll * pair, blkB = blkA + 1;
+    if constexpr (HALF == 2) {
+        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
+        h2 hx0[16], hx1[16];
+#pragma unroll
+        for (int bp = 0; bp < 16; ++bp) {
+            const uint2 v = in2[(size_t)(hi + 16 * bp) * (kN2 / 2)];
+            hx0[bp] = bits_h2(v.x);
+            hx1[bp] = bits_h2(v.y);
+        }
+        k3_tile_h16(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, hx0, hx1);
+        return;
+    }
     float2 x0[16], x1[16];
     if (HALF) {
         const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
@@ -1757,10 +1847,12 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k3_cols_inv_gen<kColsLog>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<false>, kMaxLds)
     AM_SET_LDS(k2_rows_gen<true>, kMaxLds)
-    AM_SET_LDS((k1_cols_fwd_r16<0, false>), kR16LdsK1)
-    AM_SET_LDS((k1_cols_fwd_r16<1, false>), kR16LdsK1)
-    AM_SET_LDS((k1_cols_fwd_r16<0, true>), kR16LdsK1)
-    AM_SET_LDS((k1_cols_fwd_r16<1, true>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<0, 0>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<1, 0>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<0, 1>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<1, 1>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<0, 2>), kR16LdsK1)
+    AM_SET_LDS((k1_cols_fwd_r16<1, 2>), kR16LdsK1)
     AM_SET_LDS((k1_cols_fwd_c512<0, 0>), kC512Lds)
     AM_SET_LDS((k1_cols_fwd_c512<1, 0>), kC512Lds)
     AM_SET_LDS((k1_cols_fwd_c512<0, 1>), kC512Lds)
@@ -1770,8 +1862,9 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_c512<1>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_c512<2>, kC512Lds)
-    AM_SET_LDS(k3_cols_inv_r16<false>, kR16LdsK3)
-    AM_SET_LDS(k3_cols_inv_r16<true>, kR16LdsK3)
+    AM_SET_LDS(k3_cols_inv_r16<0>, kR16LdsK3)
+    AM_SET_LDS(k3_cols_inv_r16<1>, kR16LdsK3)
+    AM_SET_LDS(k3_cols_inv_r16<2>, kR16LdsK3)
     AM_SET_LDS((k2_rows_r16<false, false>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<false, true>), kR16Lds)
     AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
@@ -1796,12 +1889,15 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
             else hipLaunchKernelGGL((k1_cols_fwd_c512<0, 0>), grid, dim3(512), kC512Lds, st, job, work, pl);
         }
     } else if (plan_is_r16(pl)) {
-        if (half) {
-            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
-            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, true>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        if (half == 2) {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, 2>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, 2>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+        } else if (half) {
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, 1>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, 1>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
         } else {
-            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, false>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
-            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, false>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+            if (pcm) hipLaunchKernelGGL((k1_cols_fwd_r16<1, 0>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
+            else hipLaunchKernelGGL((k1_cols_fwd_r16<0, 0>), grid, dim3(256), kR16LdsK1, st, job, work, pl);
         }
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
@@ -1863,9 +1959,11 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
         else hipLaunchKernelGGL(k3_cols_inv_c512<0>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
                                 pl, out_scale, scan);
     } else if (plan_is_r16(pl)) {
-        if (half) hipLaunchKernelGGL(k3_cols_inv_r16<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
-                                     pl, out_scale, scan);
-        else hipLaunchKernelGGL(k3_cols_inv_r16<false>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+        if (half == 2) hipLaunchKernelGGL(k3_cols_inv_r16<2>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+                                          pl, out_scale, scan);
+        else if (half) hipLaunchKernelGGL(k3_cols_inv_r16<1>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+                                          pl, out_scale, scan);
+        else hipLaunchKernelGGL(k3_cols_inv_r16<0>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
                                 pl, out_scale, scan);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;

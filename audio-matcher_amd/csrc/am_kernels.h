@@ -46,7 +46,7 @@ struct Segment {
 };
 
 // half: 0 = f32 work matrix; 1 = one __half2 per point, f32 butterflies; 2 = packed f16 butterflies too
-// (K2 on every plan, the column kernels on the 2^22 plan; the 2^21 column kernels keep f32 butterflies)
+// (K2 and K1 whole; K3's first pass -- its second pass and the score scan stay f32)
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, int half = 0);
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,

@@ -495,7 +495,7 @@ def side_measurements(am, device, algo, needle, params, hays, s, h, steps):
         out[name] = {"value": h * len(ptrs) / t, "unit": "samples/s", "ms_per_haystack": t / len(ptrs) * 1e3,
                      "offsets_ok": ok, "max_height_difference_to_f32": worst,
                      "note": ("option half_pipeline=1: work matrix stored as f16, f32 butterflies" if level == 1 else
-                              "option half_pipeline=2: f16 work matrix and packed-f16 butterflies (K2; K1 and K3's first pass on the 2^22 plan)")}
+                              "option half_pipeline=2: f16 work matrix and packed-f16 butterflies (K1, K2, K3's first pass)")}
         halg.close()
     # (1c) BASELINE configs[0] on the GPU: the one-chunk case the reference's own bench runs on the CPU
     # (10 s needle vs one 60 s haystack, plant at 20 s), resident, single calls -- latency, not throughput

@@ -257,9 +257,9 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *       one forward row transform of the haystack (1 = one row pass per needle)
  *   "half_pipeline" (0/1/2, BASELINE config 5; 0 = off, the default): 1 = the transform's work
  *       matrix travels through HBM in half precision, butterflies stay f32 (scores within about
- *       2e-5 on noise-like audio); 2 = the butterflies run in packed f16 as well (the row kernel
- *       on every plan, the column kernels' f16 forms on the 2^22 plan; scores within about
- *       1e-3).  Hit offsets are unaffected.  Meant for audio-level signals: full-scale input
+ *       2e-5 on noise-like audio); 2 = the butterflies run in packed f16 as well (the row kernel and
+ *       the forward column kernel whole, the first pass of the inverse column kernel; its
+ *       second pass and the score scan stay f32; scores within about 1e-3).  Hit offsets are unaffected.  Meant for audio-level signals: full-scale input
  *       stays inside f16's range, inputs far above full scale may overflow it.
  *   "dense_scores" (0/1): write every raw score from the inverse pass (threshold -inf)
  *       instead of only the tiles that can matter to the peak pick; results are
