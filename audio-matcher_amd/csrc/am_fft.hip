@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void k3_tile_h16(const Job& job, const PlanDev& pl, c
 }
 
 #ifndef AM_K3_WGS
-#define AM_K3_WGS 3   // minimum workgroups per CU the register allocation has to allow (it uses 118 VGPRs: four fit)
+#define AM_K3_WGS 3   // waves per SIMD the register allocation has to allow (= workgroups per CU for 256 threads; it uses 118 VGPRs: four fit)
 #endif
 template <int HALF>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
 __global__ void __launch_bounds__(256, AM_K3_WGS)
