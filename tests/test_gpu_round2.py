@@ -652,3 +652,38 @@ def test_non_finite_samples_cost_only_their_own_windows(gpu, oracle):
     exp_t = oracle.calc_chunks(sr, tb, tiny, pt.chunk, pt.overlap, 2.0, pt.min_distance, 5.0)
     assert [e[0] for e in exp_t] == [5 * sr, 33 * sr]
     assert_same(gpu.HipConvolve(tiny).match(tb, pt), exp_t)
+
+
+def test_profile_counters_and_pool_slots(gpu, oracle):
+    """am_profile_* (the HIP-event timing bench.py's roofline comes from) and am_pool_slot: counts
+    and times appear for the kernels that ran, a name that does not exist is an error, reset clears,
+    disabled costs nothing; a pool reports the device behind every slot."""
+    sr = 8000
+    needle = oracle.synth_uniform(9, 0, 0, 2 * sr)
+    hay = oracle.synth_uniform(9, 1, 0, 100 * sr)           # 800 000 samples: the register kernels
+    hay[43 * sr:45 * sr] += needle
+    p = gpu.Config(chunk_size_s=10.0, overlap_length_s=2.0, distance_s=5.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    algo.match(hay, p)
+    gpu.set_option("profile_mask", -1)
+    with gpu.Profile(0) as prof:
+        for _ in range(3):
+            assert [q.start for q in algo.match(hay, p)] == [43 * sr]
+        k2_ms, k2_n = prof.query("k2_rows")
+        all_ms, all_n = prof.query("*")
+        assert k2_n == 3 and 0.0 < k2_ms < 50.0
+        assert all_n >= 3 * 5 and all_ms >= k2_ms
+        for name in ("k1_cols_fwd", "k3_cols_inv", "tile_stats", "peaks"):
+            assert prof.query(name)[1] >= 3
+        with pytest.raises(gpu.AudioMatchError):
+            prof.query("no_such_kernel")
+    with gpu.Profile(0) as prof:                             # entering resets
+        assert prof.query("*")[1] == 0
+    algo.match(hay, p)                                       # disabled again: nothing is recorded
+    ms, n = C.c_double(0), C.c_uint64(0)
+    assert gpu.lib().am_profile_query(0, b"*", C.byref(ms), C.byref(n)) == 0 and n.value == 0
+    pool = gpu.Pool(needle, [0, 0, 0])
+    assert pool.size == 3 and [pool.device_of(k) for k in range(3)] == [0, 0, 0]
+    with pytest.raises(gpu.AudioMatchError):
+        pool.device_of(3)
+    pool.close()
