@@ -387,8 +387,11 @@ __device__ __forceinline__ float2 load_sample2(const void* __restrict__ src, lon
         }
         return *reinterpret_cast<const float2*>(static_cast<const float*>(src) + i);
     }
-    const int2 raw = *reinterpret_cast<const int2*>(static_cast<const short2*>(src) + i);
-    return make_float2(downmix_s16(__builtin_bit_cast(short2, raw.x)), downmix_s16(__builtin_bit_cast(short2, raw.y)));
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2* p = reinterpret_cast<const i32x2*>(static_cast<const short2*>(src) + i);
+    const i32x2 raw = AM_K1_LOAD_NT ? __builtin_nontemporal_load(p) : *p;   // (read once, like the f32 samples)
+    const int lo = raw.x, hi = raw.y;
+    return make_float2(downmix_s16(__builtin_bit_cast(short2, lo)), downmix_s16(__builtin_bit_cast(short2, hi)));
 }
 template <int KIND>
 __device__ __forceinline__ float2 load2_padded(const void* __restrict__ src, long long i, long long len) {
