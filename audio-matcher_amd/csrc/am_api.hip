@@ -1301,6 +1301,21 @@ static int correlate_impl(const am_needle* hc, const float* within, size_t w, in
     }
     const Opts o = snapshot_opts(h);
     if ((rc = run_correlation(h, o, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
+    // A NaN or an infinity in `within` makes every output of the reference's one transform per
+    // window NaN (audio_matcher.rs:414-457); overlap-save confines it to the block pairs around
+    // it.  Look at the window once and give the reference's answer.
+    {
+        const Segment whole{0, (long long)w};
+        int flag = 0;
+        if ((rc = c->ranges.ensure(sizeof(Segment)))) return rc;
+        if ((rc = c->range_flags.ensure(sizeof(int)))) return rc;
+        AM_HIP(hipMemcpyAsync(c->ranges.p, &whole, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+        AM_HIP(hipMemsetAsync(c->range_flags.p, 0, sizeof(int), c->stream));
+        AM_HIP(launch_nonfinite_ranges(c->stream, d_in, (const Segment*)c->ranges.p, 1, (int*)c->range_flags.p));
+        AM_HIP(hipMemcpyAsync(&flag, c->range_flags.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        AM_HIP(hipStreamSynchronize(c->stream));
+        if (flag) AM_HIP(hipMemsetD32Async((hipDeviceptr_t)d_out, 0x7FC00000, len, c->stream));
+    }
     AM_HIP(hipStreamSynchronize(c->stream));
     if (!device_io) AM_HIP(copy_on_stream(c, out, d_out, len * sizeof(float), hipMemcpyDeviceToHost));
     return AM_OK;

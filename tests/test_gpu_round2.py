@@ -633,6 +633,12 @@ def test_non_finite_samples_cost_only_their_own_windows(gpu, oracle):
         for _ in range(2):                                   # dense, then sparse score path
             assert_same(algo.match(bad, p), exp_bad)
         assert_same(algo.match(hay, p), exp_clean)           # and nothing sticks to the handle
+    # level 1: one window, one transform in the reference -- every output is NaN
+    win = case(30, (3, 14, 25), (12 * sr + 7,))[1]
+    for mode in (gpu.Mode.Valid, gpu.Mode.Same, gpu.Mode.Full):
+        assert np.isnan(algo.correlate_with_sample(win, mode, True)).all()
+    assert np.isnan(oracle.correlate(win, needle, oracle.MODE_VALID, oracle.SCALE_LIB)).all()
+    assert np.isfinite(algo.correlate_with_sample(win[: 12 * sr], gpu.Mode.Valid, True)).all()
     # a batch: only the bad haystack takes the slow path
     hay, bad = case(100, (13, 35, 57, 81), (34 * sr,))
     exp_clean = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
