@@ -131,7 +131,7 @@ struct Ctx {
     hipStream_t stream2 = nullptr;           // peak pick of haystack k beside the transforms of k+1 (batches)
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
-    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur, wide_ctl, wide_list;
+    DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur, wide_ctl, wide_list, wide_tiles;
     // second set of the score-side buffers: in a batch the peak pick of haystack k runs on
     // stream2 beside the transforms of haystack k+1, which then need their own set
     DevBuf scores_b, stats_b, stats32_b, wflags_b, peaks_b;
@@ -611,6 +611,9 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     wide.state = reinterpret_cast<int*>(wide.best + nsegs);
     wide.count = reinterpret_cast<unsigned*>(wide.state + nsegs);
     wide.seg_min = reinterpret_cast<float*>(wide.state + 2 * nsegs);
+    wide.ntiles = wide.state + 3 * nsegs;
+    if ((rc = c->wide_tiles.ensure((size_t)nsegs * kWideTileList * sizeof(int)))) return rc;
+    wide.tiles = static_cast<int*>(c->wide_tiles.p);
     wide.list = static_cast<am_peak*>(c->wide_list.p);
     wide.cap = AM_MAX_PEAKS_PER_CHUNK;
     {
@@ -635,12 +638,14 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
     const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
     int rc;
     if ((rc = c->wide_ctl.ensure(24))) return rc;
-    struct Ctl { unsigned long long best; int state; unsigned count; float seg_min; unsigned pad; } ctl{0ull, 1, 0u, seg_min, 0u};
+    struct Ctl { unsigned long long best; int state; unsigned count; float seg_min; int ntiles; } ctl{0ull, 7, 0u, seg_min, -1};   // (state: handed over, head and tail pieces to be scanned)
     WideState wide{};
     wide.best = static_cast<unsigned long long*>(c->wide_ctl.p);
     wide.state = reinterpret_cast<int*>(wide.best + 1);
     wide.count = reinterpret_cast<unsigned*>(wide.state + 1);
     wide.seg_min = reinterpret_cast<float*>(wide.state + 2);
+    wide.ntiles = wide.state + 3;
+    wide.tiles = nullptr;
     const Segment* d_seg = (const Segment*)c->segs.p + seg_idx;
     // pass 1: count
     wide.list = nullptr; wide.cap = 0;
@@ -1560,7 +1565,7 @@ int am_shutdown(void) {
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
                           &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b,
-                          &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur, &c->wide_ctl, &c->wide_list})
+                          &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur, &c->wide_ctl, &c->wide_list, &c->wide_tiles})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
         if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }

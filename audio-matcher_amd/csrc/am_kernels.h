@@ -120,13 +120,16 @@ struct SparseScores {
 // peaks_finish (device memory, one entry per chunk of the launch; list: AM_MAX_PEAKS_PER_CHUNK
 // entries per chunk).  list == nullptr: every chunk is finished by its one workgroup.
 struct WideState {
-    int* state;          // 0 = finished by peaks_kernel, 1 = handed over
+    int* state;          // 0 = finished by peaks_kernel; bit 0 = handed over, bits 1 / 2 = scan the raw head / tail piece
     unsigned* count;     // peaks appended to the chunk's list (> AM_MAX_PEAKS_PER_CHUNK: overflow)
     float* seg_min;
     unsigned long long* best;   // min_distance >= chunk length: running maximum of the peaks that pass (order-preserving key)
     am_peak* list;
     unsigned cap;        // entries per chunk in list (AM_MAX_PEAKS_PER_CHUNK on the usual path)
+    int* ntiles;         // candidate tiles listed for the chunk (-1: not listed, the parts test every tile)
+    int* tiles;          // kWideTileList entries per chunk: candidate tiles relative to the chunk's first full tile
 };
+constexpr int kWideTileList = 1024;
 // A chunk with more than AM_MAX_PEAKS_PER_CHUNK peaks passing the prominence filter (rare: a
 // min_distance shorter than the chunk and a tiny prominence bound).  launch_peaks_wide_one runs the
 // list-building kernel for ONE chunk (wide.state[0] must be 1; wide.cap = 0 only counts);

@@ -30,7 +30,7 @@ constexpr int kPeakThreads = 256;
 constexpr int kWaves = kPeakThreads / 64;
 constexpr int kQueueCap = kTile / 2;  // a piece of at most kTile scores has at most kTile / 2 flat-topped maxima
 constexpr int kGroup = 8;         // tiles per lane in the coarse step of a prominence walk
-constexpr int kCandCap = 1024;    // candidate tiles listed per chunk before falling back to all tiles
+constexpr int kCandCap = kWideTileList;    // candidate tiles listed per chunk before falling back to all tiles
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -610,10 +610,44 @@ __device__ void finish_best(const ChunkView& cv, unsigned long long key, am_peak
 // filters that list.  (A score array that is not white -- speech or music against a jingle --
 // has thousands of candidate maxima per chunk; one workgroup per chunk would leave 196 of
 // the 256 CUs idle for tens of milliseconds.)
-constexpr int kWideTiles = 48;
+constexpr int kWideTiles = 0;
 constexpr int kWideParts = 64;
 // a piece of at most kTile scores has at most kTile / 2 flat-topped maxima: the queue cannot overflow
 constexpr int kWideQueue = kTile / 2;
+
+// Can a peak inside full tile t reach min_prom at all?  From the tile summaries alone: a peak p in t
+// has height h <= M (the tile's maximum); its walk to one side ends at the first sample above h, at
+// the latest inside the nearest tile u on that side whose maximum exceeds M, so the minimum over its
+// walk is at least L = min of the tile minima from t to u, and
+//   prominence(p) = fl(h - max(left_min, right_min)) <= fl(M - L)       (fl is monotone).
+// One side with a stop tile and fl(M - L) < min_prom therefore settles the whole tile without a
+// look at its scores.  A score array that drifts slowly under a ripple smaller than min_prom -- what
+// a tonal or band-limited signal gives -- is rejected tile by tile this way: the uphill neighbour
+// is the stop tile.  Inconclusive (true) when neither side settles within kBoundSteps tiles or the
+// full tiles [tf, tl) of the chunk end first.
+constexpr int kBoundSteps = 32;
+// `tiles[i]` is the summary of tile tf + i (the chunk's full tiles, in LDS or in global memory).
+__device__ __forceinline__ bool tile_can_qualify(const float2* tiles, long long t, long long tf, long long tl, float min_prom) {
+    const float2* stats = tiles - tf;
+    const float2 own = stats[t];
+    const float M = own.y;
+    float L = own.x;
+    if ((M - L) >= min_prom) return true;                 // the tile's own range allows it
+    for (long long u = t - 1, n = 0; u >= tf && n < kBoundSteps; --u, ++n) {
+        const float2 v = stats[u];
+        L = fminf(L, v.x);
+        if ((M - L) >= min_prom) break;                   // this side cannot settle it any more
+        if (v.y > M) return false;
+    }
+    float R = own.x;
+    for (long long u = t + 1, n = 0; u < tl && n < kBoundSteps; ++u, ++n) {
+        const float2 v = stats[u];
+        R = fminf(R, v.x);
+        if ((M - R) >= min_prom) break;
+        if (v.y > M) return false;
+    }
+    return true;
+}
 
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
@@ -650,6 +684,13 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     const bool has_full = tl > tf;
     const long long head_hi = has_full ? tf * kTile : b;   // raw head piece [a, head_hi)
     const long long tail_lo = has_full ? tl * kTile : b;   // raw tail piece [tail_lo, b)
+    // The summaries of the chunk's full tiles go into LDS before the candidate tiles are listed, in
+    // the space of the result list (not in use before the first peak is emitted): the per-tile bound
+    // walks read them many times, one dependent load per step.
+    float2* tstats = reinterpret_cast<float2*>(res);
+    constexpr long long kStage = (long long)(sizeof(res) / (sizeof(float2)));
+    const long long nfull = has_full ? tl - tf : 0;
+    const bool staged = nfull <= kStage;
 
     // ---- chunk minimum ----------------------------------------------------
     float mn = FLT_MAX;
@@ -751,20 +792,83 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         }
     }
 
+    // (only chunks that get this far pay for the staging: a chunk without a hit left above)
+    if (staged) for (long long i = tid; i < nfull; i += kPeakThreads) tstats[i] = stats[tf + i];
+    __syncthreads();
     // ---- candidate tiles: prominence <= height - chunk_min (monotone f32
     // rounding), so a tile whose maximum fails the test cannot hold a peak ----
     if (has_full) {
         for (long long t = tf + tid; t < tl; t += kPeakThreads) {
-            if ((stats[t].y - seg_min) >= min_prom) {
+            if (!((stats[t].y - seg_min) >= min_prom)) continue;
+            if (staged ? tile_can_qualify(tstats, t, tf, tl, min_prom) : tile_can_qualify(stats + tf, t, tf, tl, min_prom)) {
                 const int slot = atomicAdd(&cand_n, 1);
                 if (slot < kCandCap) cand_tiles[slot] = (int)(t - tf);
             }
         }
     }
+    // ---- the raw head / tail piece against the full tiles inwards of it: the same bound (the piece's
+    // maximum, the minimum over the piece and the tiles up to the first one with a higher maximum)
+    __shared__ float pmm_s[4][kWaves];
+    __shared__ int piece_can_s;
+    {
+        float hmn = FLT_MAX, hmx = -FLT_MAX, tmn = FLT_MAX, tmx = -FLT_MAX;
+        if (has_full) {
+            for (long long i = a + tid; i < head_hi; i += kPeakThreads) {
+                hmn = fminf(hmn, score_for_min(g, sp, i)); hmx = fmaxf(hmx, score_for_cmp(g, sp, i));
+            }
+            for (long long i = tail_lo + tid; i < b; i += kPeakThreads) {
+                tmn = fminf(tmn, score_for_min(g, sp, i)); tmx = fmaxf(tmx, score_for_cmp(g, sp, i));
+            }
+        }
+        hmn = wave_min(hmn); hmx = wave_max(hmx); tmn = wave_min(tmn); tmx = wave_max(tmx);
+        if (lane == 0) { pmm_s[0][wv] = hmn; pmm_s[1][wv] = hmx; pmm_s[2][wv] = tmn; pmm_s[3][wv] = tmx; }
+    }
     __syncthreads();
+    if (tid == 0) {
+        int can = (head_hi > a ? 1 : 0) | (b > tail_lo ? 2 : 0);
+        if (has_full) {
+            const float2* tl_stats = staged ? tstats : stats + tf;
+            float m = FLT_MAX, M = -FLT_MAX;
+            for (int k = 0; k < kWaves; ++k) { m = fminf(m, pmm_s[0][k]); M = fmaxf(M, pmm_s[1][k]); }
+            if ((can & 1) && !((M - m) >= min_prom)) {
+                float L = m;
+                for (long long u = 0; u < nfull && u < kBoundSteps; ++u) {
+                    const float2 v = tl_stats[u];
+                    L = fminf(L, v.x);
+                    if ((M - L) >= min_prom) break;
+                    if (v.y > M) { can &= ~1; break; }
+                }
+            }
+            m = FLT_MAX; M = -FLT_MAX;
+            for (int k = 0; k < kWaves; ++k) { m = fminf(m, pmm_s[2][k]); M = fmaxf(M, pmm_s[3][k]); }
+            if ((can & 2) && !((M - m) >= min_prom)) {
+                float L = m;
+                for (long long u = nfull - 1; u >= 0 && u >= nfull - kBoundSteps; --u) {
+                    const float2 v = tl_stats[u];
+                    L = fminf(L, v.x);
+                    if ((M - L) >= min_prom) break;
+                    if (v.y > M) { can &= ~2; break; }
+                }
+            }
+        }
+        piece_can_s = can;
+    }
+    __syncthreads();
+    const int piece_can = piece_can_s;
+    if (cand_n == 0 && piece_can == 0) {   // nothing in this chunk can qualify
+        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
+        return;
+    }
     if (cand_n > kWideTiles && wide.list != nullptr) {
-        // too much for one workgroup: hand the chunk to peaks_wide / peaks_finish
-        if (tid == 0) { wide.seg_min[blockIdx.x] = seg_min; wide.count[blockIdx.x] = 0; wide.best[blockIdx.x] = 0ull; wide.state[blockIdx.x] = 1; }
+        // too much for one workgroup: hand the chunk to peaks_wide / peaks_finish, with the list of
+        // candidate tiles if it is complete (otherwise the parts test every tile themselves)
+        const bool listed = cand_n <= kCandCap;
+        if (listed) for (int i = tid; i < cand_n; i += kPeakThreads) wide.tiles[(size_t)blockIdx.x * kCandCap + i] = cand_tiles[i];
+        if (tid == 0) {
+            wide.seg_min[blockIdx.x] = seg_min; wide.count[blockIdx.x] = 0; wide.best[blockIdx.x] = 0ull;
+            wide.ntiles[blockIdx.x] = listed ? cand_n : -1;
+            wide.state[blockIdx.x] = 1 | (piece_can << 1);   // bit 0: handed over; bits 1, 2: the head / tail piece needs a scan
+        }
         return;
     }
     // more candidates than the list holds: visit every full tile instead
@@ -784,12 +888,12 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     const long long npieces = nmid + 2;
     for (long long pc = 0; pc < npieces; ++pc) {
         long long lo, hi;
-        if (pc == 0) { lo = a; hi = head_hi; }
-        else if (pc == npieces - 1) { lo = tail_lo; hi = b; }
+        if (pc == 0) { lo = a; hi = (piece_can & 1) ? head_hi : a; }
+        else if (pc == npieces - 1) { lo = tail_lo; hi = (piece_can & 2) ? b : tail_lo; }
         else {
             const long long t = tf + (all_tiles ? (pc - 1) : (long long)cand_tiles[pc - 1]);
             lo = t * kTile; hi = lo + kTile;
-            if (all_tiles && !((stats[t].y - seg_min) >= min_prom)) continue;
+            if (all_tiles && !((stats[t].y - seg_min) >= min_prom && tile_can_qualify(stats + tf, t, tf, tl, min_prom))) continue;
         }
         // (a chunk without a full tile inside has a head piece of up to 2 * kTile - 2 scores:
         // the LDS window holds kTile + halo, so long pieces go in slices)
@@ -816,7 +920,7 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
     __shared__ float win[kWin];
     __shared__ float2 wruns[kWinRuns];
     const int seg = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
-    if (wide.state[seg] != 1) return;
+    if (!(wide.state[seg] & 1)) return;
     const Segment sg = segs[seg];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     const long long tf = (a + kTile - 1) / kTile;
@@ -838,15 +942,25 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
             list[slot] = pk;
         }
     };
-    if (part == 0)
+    const int st = wide.state[seg];
+    if (part == 0 && (st & 2))
         for (long long q0 = a; q0 < head_hi; q0 += kTile)
             scan_piece(cv, q0, q0 + kTile < head_hi ? q0 + kTile : head_hi, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
-    if (part == 1 % kWideParts && b > tail_lo) scan_piece(cv, tail_lo, b, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
-    if (has_full)
-        for (long long t = tf + part; t < tl; t += kWideParts) {
-            if (!((stats[t].y - seg_min) >= min_prom)) continue;
+    if (part == 1 % kWideParts && (st & 4) && b > tail_lo) scan_piece(cv, tail_lo, b, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+    const int nlisted = wide.ntiles[seg];
+    if (has_full && nlisted >= 0) {
+        // the candidate tiles peaks_kernel found, dealt round-robin
+        const int* tiles = wide.tiles + (size_t)seg * kCandCap;
+        for (int k = part; k < nlisted; k += kWideParts) {
+            const long long t = tf + tiles[k];
             scan_piece(cv, t * kTile, (t + 1) * kTile, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
         }
+    } else if (has_full) {
+        for (long long t = tf + part; t < tl; t += kWideParts) {
+            if (!((stats[t].y - seg_min) >= min_prom && tile_can_qualify(stats + tf, t, tf, tl, min_prom))) continue;
+            scan_piece(cv, t * kTile, (t + 1) * kTile, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
+        }
+    }
     if (tid == 0 && overflow) atomicAdd(&wide.count[seg], 0x40000000u);   // (cannot happen, see kWideQueue) poisons the count
 }
 
@@ -957,7 +1071,7 @@ peaks_finish(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ int kept_s, spill_off_s;
     __shared__ long long pe_s;
     const int seg = blockIdx.x, tid = threadIdx.x;
-    if (wide.state[seg] != 1) return;
+    if (!(wide.state[seg] & 1)) return;
     am_peak* my_out = out + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
     const Segment sg = segs[seg];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
