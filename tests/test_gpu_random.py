@@ -100,3 +100,23 @@ def test_random_wide_plan(gpu, oracle, seed):
     ref = oracle.correlate(win, needle, oracle.MODE_VALID, oracle.SCALE_LIB)
     err = np.abs(got - ref)
     assert float(err.max()) < TOL, (getattr(gpu, "gpu_identity", "?"), float(err.max()), int(np.argmax(err)), s, h)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_chunks_shorter_than_the_needle_and_long_overlaps(gpu, oracle, seed):
+    """The windowing in its less usual shapes (audio_matcher.rs:99-108 puts no constraint on them):
+    chunks shorter than the needle, overlaps longer than the chunk (consecutive windows then share
+    most of their scores and a hit is reported by several of them before the merge), on the generic
+    plans and -- with the longer haystacks -- on the register kernels, whose chunk-edge logic takes
+    its general path when a chunk is shorter than a block."""
+    rng = np.random.default_rng(5000 + seed)
+    sr = 8000
+    s = int(rng.integers(3000, 9000))
+    h = int(rng.integers(20 * s, 60 * s)) if seed % 2 == 0 else int(rng.integers(600_000, 900_000))
+    needle, hay = build_case(oracle, rng, sr, s, h, int(rng.integers(2, 7)))
+    chunk = int(rng.integers(s // 4, 2 * s)) | 1
+    overlap = int(rng.choice([s, s + 1, 2 * s, s + chunk, s + 3 * chunk]))
+    prom = float(rng.choice([0.2, 0.35]))
+    dist_s = float(rng.choice([0.0, 1.0, 2.0]))
+    n = compare(gpu, oracle, needle, hay, sr, chunk, overlap, prom, dist_s)
+    assert n >= 1
