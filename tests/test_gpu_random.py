@@ -120,3 +120,41 @@ def test_random_chunks_shorter_than_the_needle_and_long_overlaps(gpu, oracle, se
     dist_s = float(rng.choice([0.0, 1.0, 2.0]))
     n = compare(gpu, oracle, needle, hay, sr, chunk, overlap, prom, dist_s)
     assert n >= 1
+
+
+@pytest.mark.parametrize("s", [1, 2, 3, 50, 63, 64, 65, 66, 200])
+def test_needle_lengths_around_the_direct_summation_limit(gpu, oracle, s):
+    """Needles of up to 64 samples are summed directly, longer ones take the transforms: every mode
+    and scaling of level 1, and level 2 (windows of several chunks, pcm16 and f32 ingest), on both
+    sides of the switch, against the checker."""
+    rng = np.random.default_rng(7000 + s)
+    sr = 8000
+    needle = oracle.synth_uniform(700 + s, 0, 0, s)
+    hay = oracle.synth_uniform(700 + s, 1, 0, 40 * sr)
+    plants = [int(x) for x in (3.3 * sr, 17.0 * sr + 5, 29.9 * sr)]
+    for o in plants:
+        hay[o:o + s] += 3.0 * needle
+    algo = gpu.HipConvolve(needle)
+    win = hay[: 9000 + s]
+    for mode, omode in ((gpu.Mode.Full, oracle.MODE_FULL), (gpu.Mode.Same, oracle.MODE_SAME), (gpu.Mode.Valid, oracle.MODE_VALID)):
+        for scale, oscale in ((False, oracle.SCALE_NONE), (True, oracle.SCALE_LIB)):
+            got = algo.correlate_with_sample(win, mode, scale)
+            ref = oracle.correlate(win, needle, omode, oscale)
+            assert got.shape == ref.shape and np.abs(got - ref).max() < TOL * max(1.0, float(np.abs(ref).max()))
+    chunk, overlap = 7 * sr + 1, s + 11
+    prom = 1.5                                          # planted at gain 3: scaled score about 3
+    n = compare(gpu, oracle, needle, hay, sr, chunk, overlap, prom, 2.0, handle=algo)
+    assert n >= 1
+    # the same through the i16 stereo ingest
+    lr = np.clip(np.round(np.repeat(hay, 2) * 20000.0), -32768, 32767).astype(np.int16)
+    nlr = np.clip(np.round(np.repeat(needle, 2) * 20000.0), -32768, 32767).astype(np.int16)
+    a16 = gpu.HipConvolve.from_pcm16(nlr)
+    m_needle, m_hay = oracle.pcm_s16_stereo_to_mono(nlr), oracle.pcm_s16_stereo_to_mono(lr)
+    if float(np.sum(m_needle.astype(np.float64) ** 2)) > 0.0:
+        p = gpu.AmMatchParams(sr=sr, chunk=chunk, overlap=overlap, min_prominence=prom, min_distance=2 * sr,
+                              overshadow_distance_s=2.0, scale=1)
+        exp = oracle.calc_chunks(sr, m_hay, m_needle, chunk, overlap, prom, p.min_distance, 2.0)
+        got = a16.match_pcm16(lr, p)
+        assert [(g.start, g.end) for g in got] == [(x[0], x[1]) for x in exp]
+        for g, x in zip(got, exp):
+            assert abs(g.height - x[2]) < TOL * 3 and abs(g.prominence - x[3]) < TOL * 3
