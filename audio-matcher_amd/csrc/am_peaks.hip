@@ -773,9 +773,37 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
             }
             __syncthreads();
             if (fast_s) {
+                // Nothing in the chunk is higher than its maximum, so both walks run to the chunk edges:
+                // prominence = M - max(min[a, pi), min[plateau end, b)), as two reductions by the whole
+                // workgroup (raw scores up to the first and from the last full tile of either range, tile
+                // summaries in between) instead of a walk by one wavefront.  A minimum does not depend on
+                // the order it is taken in: the same bits as prominence().
+                __shared__ float side_s[2][kWaves];
+                const long long pk_end = peak_k_s;
+                float lm = M, rm = M;
+                {
+                    auto range_min = [&](long long lo, long long hi) {
+                        float m = FLT_MAX;
+                        long long t0 = (lo + kTile - 1) / kTile, t1 = hi / kTile;   // whole tiles inside [lo, hi)
+                        if (t0 < tf) t0 = tf;
+                        if (t1 > tl) t1 = tl;
+                        if (!has_full || t0 >= t1) {
+                            for (long long i = lo + tid; i < hi; i += kPeakThreads) m = fminf(m, score_for_min(g, sp, i));
+                            return m;
+                        }
+                        for (long long i = lo + tid; i < t0 * kTile; i += kPeakThreads) m = fminf(m, score_for_min(g, sp, i));
+                        for (long long t = t0 + tid; t < t1; t += kPeakThreads) m = fminf(m, stats[t].x);
+                        for (long long i = t1 * kTile + tid; i < hi; i += kPeakThreads) m = fminf(m, score_for_min(g, sp, i));
+                        return m;
+                    };
+                    const float l = wave_min(range_min(a, pi)), r = wave_min(range_min(pk_end, b));
+                    if (lane == 0) { side_s[0][wv] = l; side_s[1][wv] = r; }
+                }
+                __syncthreads();
                 if (wv == 0) {
-                    float prom = 0.0f;
-                    const bool keep = prominence(g, stats, sp, a, b, pi, peak_k_s, M, min_prom, lane, prom);
+                    for (int k = 0; k < kWaves; ++k) { lm = fminf(lm, side_s[0][k]); rm = fminf(rm, side_s[1][k]); }
+                    const float prom = M - fmaxf(lm, rm);
+                    const bool keep = prom >= min_prom;
                     if (lane == 0) {
                         if (keep) {
                             am_peak pk; pk.start = (uint64_t)pi; pk.end = (uint64_t)peak_k_s; pk.height = M; pk.prominence = prom;
