@@ -719,7 +719,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     //     peak in (height descending, position ascending) order that passes the prominence
     //     test and drops all others.  The chunk's maximum -- at its first position -- is
     //     first in that order, so if it is a peak and passes, it is the chunk's whole answer
-    //     after ONE prominence walk, however many other maxima would qualify.  Anything else
+    //     after ONE prominence evaluation, however many other maxima would qualify.  Anything else
     //     (maximum at a chunk edge, a plateau reaching the edge, insufficient prominence)
     //     falls through to the general path below.
     {
