@@ -218,10 +218,12 @@ def strong_batch(am, R, device, algo, needle, params, total, steps, s, h, ranks_
     bufs = [am.DeviceBuffer(device, 4 * h) for _ in range(n_buf)]
     local = 0.0
     resident = None
+    # every rank goes through the same number of waves (an empty one still takes part in the barrier)
+    n_waves = max(1, int(R.max_all(float((len(mine) + n_buf - 1) // n_buf))))
     for _ in range(steps):
-        for w0 in range(0, max(len(mine), 1), n_buf):
-            wave = mine[w0:w0 + n_buf]
-            if wave != resident:                      # a shard that fits one wave is generated once
+        for wi in range(n_waves):
+            wave = mine[wi * n_buf:(wi + 1) * n_buf]
+            if wave and wave != resident:             # a shard that fits one wave is generated once
                 for b, k in zip(bufs, wave):
                     fill_haystack(am, device, b, k, needle.ptr, s, h)
                 resident = wave
