@@ -760,8 +760,14 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
         int rc = plan_geometry(h->n, out_count, o, &g);
         if (rc) return rc;
         npairs = g.npairs;
-        for (long long q = 0; q < npairs; ++q)   // blocks 2q, 2q+1 read samples [2q hop, (2q+2) hop + s - 1)
-            ranges.push_back(Segment{2 * q * g.hop, std::min<long long>((long long)len, (2 * q + 2) * g.hop + s - 1)});
+        // K1 loads a full N samples per block, starting at block * hop (am_fft.hip, k1_cols_fwd_*), and hop
+        // may have been rounded down to a multiple of kTile: pair q reads [2q hop, (2q + 1) hop + N), or
+        // [2q hop, 2q hop + N) when its second block does not exist -- up to kTile - 1 samples more than
+        // the scores it yields depend on, and a NaN there still poisons the whole pair
+        for (long long q = 0; q < npairs; ++q) {
+            const long long last_block = (2 * q + 1 < g.nblocks) ? 2 * q + 1 : 2 * q;
+            ranges.push_back(Segment{2 * q * g.hop, std::min<long long>((long long)len, last_block * g.hop + g.N)});
+        }
     }
     int rc;
     if ((rc = c->ranges.ensure(sizeof(Segment) * ranges.size()))) return rc;
@@ -783,10 +789,10 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
 
 static int match_many(am_needle* h, const void* const* d_hays, const size_t* lens, size_t n_hay,
                       const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0,
-                      size_t index_base = 0, size_t index_stride = 1) {
+                      size_t index_base = 0, size_t index_stride = 1, bool fire_hooks = true) {
     Ctx* c = h->ctx;
     const Opts o = snapshot_opts(h);
-    const Hooks hooks = snapshot_hooks();
+    const Hooks hooks = fire_hooks ? snapshot_hooks() : Hooks{};
     // local haystack k is item G(k) of the caller's batch: out, n_out and the progress
     // callbacks use that index (pool submit threads pass their shard: base + k * stride)
     auto G = [&](size_t k) { return index_base + k * index_stride; };
@@ -848,6 +854,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // the previous pick still runs on the other stream
     if ((rc = c->wide_ctl.ensure(max_segs * 24))) return rc;
     if ((rc = c->wide_list.ensure(max_segs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    if ((rc = c->wide_tiles.ensure(max_segs * kWideTileList * sizeof(int)))) return rc;
     if ((rc = c->stats.ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
     if (overlap) {
         if ((rc = c->stats_b.ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
@@ -866,7 +873,8 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // and one local slice as long as a full chunk, for chunks that are correlated again on their
     // own window (non-finite samples nearby, below); the pick clamps it to the scores there are
     const int local_seg = (int)resident.size();
-    { Segment local; local.a = 0; local.b = std::max<long long>(scan.seg_d, 1); resident.push_back(local); }
+    // (seg_d is the index of a full window's LAST score: chunk + overlap - s + 1 scores in all)
+    { Segment local; local.a = 0; local.b = std::max<long long>(scan.seg_d + 1, 1); resident.push_back(local); }
     if ((rc = upload_segments(c, resident))) return rc;
     if ((rc = c->badflag.ensure(sizeof(int) * n_hay))) return rc;
     int* h_bad = static_cast<int*>(c->badflag.p);
@@ -1019,128 +1027,207 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
 }
 
 
-// BASELINE config 4: several needles against one resident haystack.  The
-// haystack's forward column pass (K1) runs once; needles are then taken in groups
-// that share the forward row transforms of K2 (k2_rows_r16_group), each needle
-// with its own inverse rows, K3 (fused scan) and peak pick.  Needles must share
-// one length so that they share the block layout.
-static int match_multi(am_needle* const* needles, size_t nn, const void* d_hay, size_t len, int src_kind,
-                       const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out) {
+// BASELINE config 4: several needles against a batch of resident haystacks = the per-file loop of
+// matcher::run (matcher/mod.rs:42-87) around N snippets.  Per haystack the forward column pass (K1)
+// runs once; needles are then taken in groups that share the forward row transforms of K2
+// (k2_rows_r16_group), each needle with its own inverse rows, K3 (fused scan) and peak pick.  The
+// pick of (haystack, needle) runs on the second stream beside the next needle's K3 / the next
+// haystack's K1 and K2; the score-side buffers alternate between two sets, as in match_many.
+// Needles must share one length so that they share the block layout.
+// Result slot of (haystack k of the caller's batch, needle j): G(k) * nn + j.
+static int match_multi_many(am_needle* const* needles, size_t nn, const void* const* d_hays, const size_t* lens, size_t n_hay,
+                            int src_kind, const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out,
+                            size_t index_base = 0, size_t index_stride = 1) {
     am_needle* h0 = needles[0];
     Ctx* c = h0->ctx;
     const Opts o = snapshot_opts(h0);
+    const Hooks hooks = snapshot_hooks();
+    auto G = [&](size_t k) { return index_base + k * index_stride; };
     const size_t s = h0->n;
-    for (size_t k = 0; k < nn; ++k) {
-        n_out[k] = 0;
-        if (!needles[k] || needles[k]->ctx != c) return fail(AM_ERR_INVALID_ARG, "needles must live on one device");
-        if (needles[k]->n != s) return fail(AM_ERR_INVALID_ARG, "am_match_multi: needles must have equal length");
+    for (size_t j = 0; j < nn; ++j) {
+        if (!needles[j] || needles[j]->ctx != c) return fail(AM_ERR_INVALID_ARG, "needles must live on one device");
+        if (needles[j]->n != s) return fail(AM_ERR_INVALID_ARG, "am_match_multi: needles must have equal length");
     }
     if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
     if (p->scale != AM_SCALE_NONE && p->scale != AM_SCALE_LIB)
         return fail(AM_ERR_INVALID_ARG, "am_match_multi supports AM_SCALE_NONE and AM_SCALE_LIB");
-    if (len < s) return AM_OK;
+    for (size_t k = 0; k < n_hay; ++k)
+        for (size_t j = 0; j < nn; ++j) n_out[G(k) * nn + j] = 0;
     const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
+    // the chunk lists of every haystack, back to back, and each haystack's block layout
     std::vector<Segment> segs;
-    make_segments(len, s, p, segs);
-    const int nsegs = (int)segs.size();
-    if (nsegs == 0) return AM_OK;
-    const long long out_count = (long long)(len - s + 1);
+    std::vector<int> seg_off(n_hay + 1, 0);
+    std::vector<Geometry> geo(n_hay);
+    size_t max_scores = 0, max_segs = 1, max_work = 0, max_matrix = 0, max_wflags = 0;
     int rc;
-    Geometry g{};
-    if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
-    const Plan* pl = nullptr;
-    if ((rc = get_plan(c, g.logN, &pl))) return rc;
-    const long long N = g.N, hop = g.hop, nblocks = g.nblocks, npairs = g.npairs;
-    std::vector<const float2*> hcs(nn);
-    for (size_t k = 0; k < nn; ++k)
-        if ((rc = needle_spectrum(needles[k], pl, &hcs[k]))) return rc;   // may use c->work: before it is filled
-    if ((rc = c->work.ensure((size_t)npairs * (size_t)N * sizeof(float2)))) return rc;
-    const int half = (o.half && (plan_is_r16(pl->dev) || plan_is_c512(pl->dev))) ? (o.half >= 2 ? 2 : 1) : 0;
-    // needles are taken in groups that share the forward row transforms of K2
-    const size_t group = (!half && plan_k2_has_group(pl->dev))
-        ? (size_t)std::min<long long>(std::max<long long>(1, o.needle_group), kMaxNeedleGroup) : 1;
-    const size_t matrix = (size_t)npairs * (size_t)N;   // points of one needle's work matrix
-    if ((rc = c->work2.ensure(std::min(group, nn) * matrix * sizeof(float2)))) return rc;
-    if ((rc = c->scores.ensure((size_t)out_count * sizeof(float)))) return rc;
-    if ((rc = c->peaks.ensure(sizeof(am_peak) * (size_t)nsegs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
-    PeakArena arena{};
-    if ((rc = prepare_results(c, (size_t)nsegs * nn, (size_t)nsegs * nn * 8 + 4096, &arena))) return rc;
-    if ((rc = upload_segments(c, segs))) return rc;
-    SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
-    const bool fused = plan_has_scan(pl->dev) && (hop % kTile) == 0;
-    if (fused) {
-        if ((rc = c->stats32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-        if ((rc = c->wflags.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
+    for (size_t k = 0; k < n_hay; ++k) {
+        seg_off[k] = (int)segs.size();
+        if (!d_hays[k] || lens[k] < s) continue;
+        make_segments(lens[k], s, p, segs);
+        const size_t ns = segs.size() - (size_t)seg_off[k];
+        if (ns == 0) continue;
+        const long long out_count = (long long)(lens[k] - s + 1);
+        if ((rc = plan_geometry(s, out_count, o, &geo[k]))) return rc;
+        const size_t matrix = (size_t)geo[k].npairs * (size_t)geo[k].N;
+        max_scores = std::max(max_scores, (size_t)out_count);
+        max_segs = std::max(max_segs, ns);
+        max_work = std::max(max_work, matrix);
+        max_matrix = std::max(max_matrix, matrix);
+        max_wflags = std::max(max_wflags, (size_t)geo[k].nblocks << 8);   // (at most 2^13 / 32 column tiles per block)
     }
-    Job job{};
-    job.src = d_hay; job.src_len = (long long)len; job.lead = 0; job.src_kind = src_kind;
-    job.dst = (float*)c->scores.p; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
-    job.first_pair = 0;
-    { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)npairs, (float2*)c->work.p, pl->dev, half)); }
-    for (size_t k = 0; k < nn; ++k) {
-        am_needle* h = needles[k];
-        const size_t in_group = k % group;
-        const float2* inv_rows = (const float2*)c->work2.p + in_group * matrix;   // this needle's inverse rows
-        if (group > 1 && in_group == 0) {
-            K2Group grp{};
-            grp.n = (int)std::min(group, nn - k);
-            for (int j = 0; j < grp.n; ++j) { grp.hc[j] = hcs[k + j]; grp.dst[j] = (float2*)c->work2.p + (size_t)j * matrix; }
-            ProfScope ps(c, KN_K2);
-            AM_HIP(launch_k2_group(c->stream, (int)npairs, (const float2*)c->work.p, grp, pl->dev));
+    seg_off[n_hay] = (int)segs.size();
+    const size_t nsegs = segs.size();
+    if (nsegs == 0) return AM_OK;
+    if (max_segs > (size_t)1 << 18 || nsegs * nn > (size_t)1 << 24)
+        return fail(AM_ERR_INVALID_ARG, "chunk size too small for this batch (too many chunks)");
+    // every needle's spectrum for every plan in use, before the work matrix is filled (building one uses it)
+    std::map<int, std::vector<const float2*>> hcs;
+    for (size_t k = 0; k < n_hay; ++k) {
+        if (seg_off[k + 1] == seg_off[k] || hcs.count(geo[k].logN)) continue;
+        const Plan* pl = nullptr;
+        if ((rc = get_plan(c, geo[k].logN, &pl))) return rc;
+        std::vector<const float2*>& v = hcs[geo[k].logN];
+        v.resize(nn);
+        for (size_t j = 0; j < nn; ++j) {
+            if ((rc = needle_spectrum(needles[j], pl, &v[j]))) return rc;
+            const HalfScale hs = half_scale(needles[j], o, pl->dev);
+            if (hs.level == 2 && (rc = needle_spectrum16(needles[j], pl, hs.hscale, &v[j]))) return rc;
         }
-        ScanRequest scan{};
-        scan.theta = (!o.dense && h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
-        scan.seg_c = (long long)p->chunk;
-        scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
-        scan.fused = fused;
-        scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
-        ScanCfg cfg{};
-        if (fused) {
-            cfg.stats32 = (float2*)c->stats32.p; cfg.wflags = (unsigned char*)c->wflags.p; cfg.theta = scan.theta;
-            cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
-            scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+    }
+    const size_t group_opt = (size_t)std::min<long long>(std::max<long long>(1, o.needle_group), kMaxNeedleGroup);
+    size_t n_pairs_active = 0;
+    for (size_t k = 0; k < n_hay; ++k) n_pairs_active += seg_off[k + 1] > seg_off[k] ? nn : 0;
+    const bool overlap = o.batch_overlap && n_pairs_active > 1 && c->stream2 &&
+                         c->ev_k3[0] && c->ev_k3[1] && c->ev_pick[0] && c->ev_pick[1];
+    if ((rc = c->work.ensure(max_work * sizeof(float2)))) return rc;
+    if ((rc = c->work2.ensure(std::min(group_opt, nn) * max_matrix * sizeof(float2)))) return rc;
+    for (int set = 0; set < (overlap ? 2 : 1); ++set) {
+        if ((rc = (set ? c->scores_b : c->scores).ensure(max_scores * sizeof(float)))) return rc;
+        if ((rc = (set ? c->peaks_b : c->peaks).ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
+        if ((rc = (set ? c->stats_b : c->stats).ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
+        if ((rc = (set ? c->stats32_b : c->stats32).ensure((max_scores + 31) / 32 * sizeof(float2)))) return rc;
+        if ((rc = (set ? c->wflags_b : c->wflags).ensure(max_wflags))) return rc;
+    }
+    if ((rc = c->wide_ctl.ensure(max_segs * 24))) return rc;
+    if ((rc = c->wide_list.ensure(max_segs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    if ((rc = c->wide_tiles.ensure(max_segs * kWideTileList * sizeof(int)))) return rc;
+    PeakArena arena{};
+    if ((rc = prepare_results(c, nsegs * nn, nsegs * nn * 8 + 4096, &arena))) return rc;
+    if ((rc = upload_segments(c, segs))) return rc;
+    if ((rc = c->badflag.ensure(sizeof(int) * n_hay))) return rc;
+    int* h_bad = static_cast<int*>(c->badflag.p);
+    memset(h_bad, 0, sizeof(int) * n_hay);
+    SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
+    // result headers of (haystack k, needle j): nsegs entries per needle, the haystack's slice inside
+    auto hdr_of = [&](size_t k, size_t j) { return (int)(j * nsegs) + seg_off[k]; };
+    size_t seq = 0;
+    for (size_t k = 0; k < n_hay; ++k) {
+        const int ns = seg_off[k + 1] - seg_off[k];
+        if (ns == 0) continue;
+        if (hooks.fn) hooks.fn(hooks.user, G(k), 0, (size_t)ns);
+        const Geometry& g = geo[k];
+        const Plan* pl = nullptr;
+        if ((rc = get_plan(c, g.logN, &pl))) return rc;
+        const std::vector<const float2*>& hc = hcs[g.logN];
+        const long long out_count = (long long)(lens[k] - s + 1);
+        const int half = (o.half && (plan_is_r16(pl->dev) || plan_is_c512(pl->dev))) ? (o.half >= 2 ? 2 : 1) : 0;
+        const size_t group = (!half && plan_k2_has_group(pl->dev)) ? group_opt : 1;
+        const size_t matrix = (size_t)g.npairs * (size_t)g.N;
+        const bool fused = plan_has_scan(pl->dev) && (g.hop % kTile) == 0;
+        Job job{};
+        job.src = d_hays[k]; job.src_len = (long long)lens[k]; job.lead = 0; job.src_kind = src_kind;
+        job.out_count = out_count; job.hop = (int)g.hop; job.nblocks = (int)g.nblocks; job.first_pair = 0;
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)g.npairs, (float2*)c->work.p, pl->dev, half)); }
+        for (size_t j = 0; j < nn; ++j) {
+            am_needle* h = needles[j];
+            const size_t in_group = j % group;
+            const float2* inv_rows = (const float2*)c->work2.p + in_group * matrix;   // this needle's inverse rows
+            if (group > 1 && in_group == 0) {
+                K2Group grp{};
+                grp.n = (int)std::min(group, nn - j);
+                for (int q = 0; q < grp.n; ++q) { grp.hc[q] = hc[j + q]; grp.dst[q] = (float2*)c->work2.p + (size_t)q * matrix; }
+                ProfScope ps(c, KN_K2);
+                AM_HIP(launch_k2_group(c->stream, (int)g.npairs, (const float2*)c->work.p, grp, pl->dev));
+            }
+            const int set = overlap ? (int)(seq & 1) : 0;
+            float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
+            job.dst = d_scores;
+            ScanRequest scan{};
+            scan.set = set;
+            scan.theta = (!o.dense && h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+            scan.seg_c = (long long)p->chunk;
+            scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
+            scan.bad = src_kind == 0 ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
+            scan.fused = fused;
+            scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)g.hop, pl->dev.logN2, 1.0 / (double)g.hop};
+            ScanCfg cfg{};
+            if (fused) {
+                cfg.stats32 = (float2*)(set ? c->stats32_b.p : c->stats32.p);
+                cfg.wflags = (unsigned char*)(set ? c->wflags_b.p : c->wflags.p);
+                cfg.theta = scan.theta;
+                cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
+                scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)g.hop, pl->dev.logN2, 1.0 / (double)g.hop};
+            }
+            const float factor = scale_factor(h, p->scale, 1);
+            const HalfScale hs = half_scale(h, o, pl->dev);
+            if (group == 1) {
+                ProfScope ps(c, KN_K2);
+                AM_HIP(launch_k2(c->stream, (int)g.npairs, (float2*)c->work.p, hc[j], pl->dev, (float2*)c->work2.p, hs.level, hs.hscale, hs.pre));
+            }
+            // K3 overwrites this set's scores and summaries: the pick that last read them must be done
+            if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
+            { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)g.npairs, inv_rows, pl->dev, hs.k3(factor), cfg, half)); }
+            if (overlap) {
+                AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
+                AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
+            }
+            if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
+                                  &scan, hdr_of(k, j), arena, overlap ? c->stream2 : c->stream))) return rc;
+            if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
+            ++seq;
         }
-        const float factor = scale_factor(h, p->scale, 1);
-        const HalfScale hs = half_scale(h, o, pl->dev);
-        if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hcs[k]))) return rc;
-        if (group == 1) { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, (int)npairs, (float2*)c->work.p, hcs[k], pl->dev, (float2*)c->work2.p, hs.level, hs.hscale, hs.pre)); }
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)npairs, inv_rows, pl->dev,
-                                                  hs.k3(factor), cfg, half)); }
-        if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, 0, nsegs, p->min_prominence,
-                              (long long)p->min_distance, &scan, (int)(k * nsegs), arena))) return rc;
     }
     AM_HIP(hipStreamSynchronize(c->stream));
+    if (overlap) AM_HIP(hipStreamSynchronize(c->stream2));
     int worst = AM_OK;
     std::vector<am_peak> all;
-    for (size_t k = 0; k < nn; ++k) {
-        am_needle* h = needles[k];
-        const SegHeader* hd = h_hdr + k * nsegs;
-        bool redo = false;
-        for (int i = 0; i < nsegs; ++i) {
-            if (hd[i].overflow & 7) redo = true;   // (bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks -- the single-needle path lists them all)
-            if (!h->have_min[sm] || hd[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = hd[i].seg_min; h->have_min[sm] = true; }
-        }
-        all.clear();
-        if (!redo)
-            for (int i = 0; i < nsegs; ++i) append_header_peaks(hd[i], arena, all);
-        if (!redo) {
-            rc = merge_peaks(all, p, out ? out + k * cap_per_needle : nullptr, cap_per_needle, &n_out[k]);
+    std::vector<std::pair<size_t, size_t>> redo;
+    for (size_t k = 0; k < n_hay; ++k) {
+        const int ns = seg_off[k + 1] - seg_off[k];
+        if (ns == 0) continue;
+        for (size_t j = 0; j < nn; ++j) {
+            am_needle* h = needles[j];
+            const SegHeader* hd = h_hdr + hdr_of(k, j);
+            const size_t slot = G(k) * nn + j;
+            // Non-finite samples poison whole block pairs for every needle (see match_many): such a
+            // haystack goes through the single-needle path, which gives every window the reference's
+            // answer, and teaches the write threshold nothing.  So does a pair with a failed
+            // certificate, a lost spill or more than AM_MAX_PEAKS_PER_CHUNK peaks in a chunk.
+            bool again = h_bad[k] != 0;
+            for (int i = 0; i < ns && !h_bad[k]; ++i) {
+                if (hd[i].overflow & 7) again = true;
+                if (!h->have_min[sm] || hd[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = hd[i].seg_min; h->have_min[sm] = true; }
+            }
+            if (again) { redo.emplace_back(k, j); continue; }
+            all.clear();
+            for (int i = 0; i < ns; ++i) append_header_peaks(hd[i], arena, all);
+            rc = merge_peaks(all, p, out ? out + slot * cap_per_pair : nullptr, cap_per_pair, &n_out[slot]);
             if (rc == AM_ERR_CAPACITY) worst = rc;
             else if (rc) return rc;
-        } else {
-            n_out[k] = (size_t)-1;   // marked: redone below, once the shared result area is no longer needed
         }
     }
-    // rare: a needle with a failed certificate or a lost spill goes through the single-needle
-    // path (which redoes exactly the chunks that need it); this reuses the result area, so
-    // it runs after every other needle has been collected
-    for (size_t k = 0; k < nn; ++k) {
-        if (n_out[k] != (size_t)-1) continue;
-        n_out[k] = 0;
-        rc = match_many(needles[k], &d_hay, &len, 1, p, out ? out + k * cap_per_needle : nullptr, cap_per_needle, &n_out[k], src_kind);
+    // the single-needle path reuses the result area: it runs after everything else has been collected
+    for (const auto& kj : redo) {
+        const size_t slot = G(kj.first) * nn + kj.second;
+        n_out[slot] = 0;
+        rc = match_many(needles[kj.second], &d_hays[kj.first], &lens[kj.first], 1, p, out ? out + slot * cap_per_pair : nullptr,
+                        cap_per_pair, &n_out[slot], src_kind, 0, 1, false);
         if (rc == AM_ERR_CAPACITY) worst = rc;
         else if (rc) return rc;
     }
+    if (hooks.fn)
+        for (size_t k = 0; k < n_hay; ++k)
+            if (seg_off[k + 1] > seg_off[k]) hooks.fn(hooks.user, G(k), 1, (size_t)(seg_off[k + 1] - seg_off[k]));
     return worst;
 }
 
@@ -1195,7 +1282,8 @@ using namespace am;
 struct am_pool {
     struct Slot {
         int device = -1;
-        am_needle* needle = nullptr;
+        am_needle* needle = nullptr;           // needles[0]
+        std::vector<am_needle*> needles;       // every needle of the pool, replicated on this device
         // two-slot HBM ring + copy stream of the host-buffer path
         void* ring[2] = {nullptr, nullptr};
         size_t ring_cap = 0;
@@ -1385,7 +1473,25 @@ int am_match_multi_device(const am_needle* const* needles, size_t n_needles, con
     int rc = check_needle(h0);
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(h0->ctx->mu);
-    return match_multi(const_cast<am_needle* const*>(needles), n_needles, d_haystack, len, 0, p, out, cap_per_needle, n_out);
+    const void* src = d_haystack;
+    return match_multi_many(const_cast<am_needle* const*>(needles), n_needles, &src, &len, 1, AM_FMT_F32_MONO, p, out, cap_per_needle, n_out);
+}
+
+int am_match_multi_batch_device(const am_needle* const* needles, size_t n_needles, const void* const* d_haystacks,
+                                const size_t* lens, size_t n_hay, int sample_format, const am_match_params* p,
+                                am_peak* out, size_t cap_per_pair, size_t* n_out) {
+    if (!needles || n_needles == 0 || !d_haystacks || !lens || !p || !n_out || (!out && cap_per_pair))
+        return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (sample_format != AM_FMT_F32_MONO && sample_format != AM_FMT_S16_STEREO) return fail(AM_ERR_INVALID_ARG, "bad sample format");
+    for (size_t k = 0; k < n_needles; ++k)
+        if (!needles[k] || !needles[k]->ctx) return fail(AM_ERR_INVALID_ARG, "null needle handle");
+    am_needle* h0 = const_cast<am_needle*>(needles[0]);
+    int rc = check_needle(h0);
+    if (rc) return rc;
+    if (n_hay == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(h0->ctx->mu);
+    return match_multi_many(const_cast<am_needle* const*>(needles), n_needles, d_haystacks, lens, n_hay, sample_format, p,
+                            out, cap_per_pair, n_out);
 }
 
 // ---- the same three entry points on interleaved i16 stereo PCM: the down-mix of
@@ -1593,8 +1699,9 @@ int am_shard_plan(size_t n_items, size_t n_shards, size_t shard, size_t* first, 
     return AM_OK;
 }
 
-int am_pool_create(const float* needle, size_t n, const int* devices, size_t n_dev, am_pool** out) {
-    if (!needle || !out || n == 0) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+static int pool_create_common(const float* const* needles, size_t n_needles, size_t n, const int* devices, size_t n_dev, am_pool** out) {
+    if (!needles || !out || n == 0 || n_needles == 0) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+    for (size_t j = 0; j < n_needles; ++j) if (!needles[j]) return fail(AM_ERR_INVALID_ARG, "null needle");
     std::vector<int> devs;
     if (devices) {
         if (n_dev == 0) return fail(AM_ERR_INVALID_ARG, "empty device list");
@@ -1609,7 +1716,13 @@ int am_pool_create(const float* needle, size_t n, const int* devices, size_t n_d
     for (size_t i = 0; i < devs.size(); ++i) {
         am_pool::Slot& sl = pool->slots[i];
         sl.device = devs[i];
-        int rc = am_needle_create(devs[i], needle, n, &sl.needle);
+        int rc = AM_OK;
+        for (size_t j = 0; j < n_needles && rc == AM_OK; ++j) {
+            am_needle* h = nullptr;
+            rc = am_needle_create(devs[i], needles[j], n, &h);
+            if (rc == AM_OK) sl.needles.push_back(h);
+        }
+        if (rc == AM_OK) sl.needle = sl.needles[0];
         if (rc == AM_OK && hipStreamCreateWithFlags(&sl.copy_stream, hipStreamNonBlocking) != hipSuccess)
             rc = fail(AM_ERR_HIP, "hipStreamCreate(pool copy stream)");
         if (rc) { const std::string keep = t_err; am_pool_destroy(pool); t_err = keep; return rc; }
@@ -1618,13 +1731,22 @@ int am_pool_create(const float* needle, size_t n, const int* devices, size_t n_d
     return AM_OK;
 }
 
+int am_pool_create(const float* needle, size_t n, const int* devices, size_t n_dev, am_pool** out) {
+    if (!needle) return fail(AM_ERR_INVALID_ARG, "needle must be non-empty");
+    return pool_create_common(&needle, 1, n, devices, n_dev, out);
+}
+
+int am_pool_create_multi(const float* const* needles, size_t n_needles, size_t n, const int* devices, size_t n_dev, am_pool** out) {
+    return pool_create_common(needles, n_needles, n, devices, n_dev, out);
+}
+
 void am_pool_destroy(am_pool* pool) {
     if (!pool) return;
     for (am_pool::Slot& sl : pool->slots) {
         if (sl.device >= 0) (void)hipSetDevice(sl.device);
         if (sl.copy_stream) { (void)hipStreamSynchronize(sl.copy_stream); (void)hipStreamDestroy(sl.copy_stream); }
         for (void* r : sl.ring) if (r) (void)hipFree(r);
-        am_needle_destroy(sl.needle);
+        for (am_needle* h : sl.needles) am_needle_destroy(h);
     }
     delete pool;
 }
@@ -1644,25 +1766,39 @@ int am_pool_slot(const am_pool* pool, size_t slot, int* device, const am_needle*
 
 namespace {
 
-// resident haystacks: the slot's shard goes through match_many as one batch
-int slot_run_device(am_pool::Slot& sl, size_t slot, size_t nslots, const float* const* d_hays, const size_t* lens, size_t n_hay,
-                    const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+// What a pool call runs per haystack: one needle (match_many; out holds cap slots per haystack) or
+// every needle of the pool (match_multi_many; cap slots per (haystack, needle) pair, slot k * nn + j).
+struct PoolJob {
+    bool multi;
+    int fmt;   // AM_FMT_*: one f32 mono sample and one i16 stereo frame are both 4 bytes
+};
+
+int slot_match(am_pool::Slot& sl, const PoolJob& job, const void* const* ptrs, const size_t* ln, size_t count,
+               const am_match_params* p, am_peak* out, size_t cap, size_t* n_out, size_t first, size_t stride) {
+    am_needle* h = sl.needle;
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    if (job.multi)
+        return match_multi_many(sl.needles.data(), sl.needles.size(), ptrs, ln, count, job.fmt, p, out, cap, n_out, first, stride);
+    return match_many(h, ptrs, ln, count, p, out, cap, n_out, job.fmt, first, stride);
+}
+
+// resident haystacks: the slot's shard goes through the matcher as one batch
+int slot_run_device(am_pool::Slot& sl, const PoolJob& job, size_t slot, size_t nslots, const void* const* d_hays, const size_t* lens,
+                    size_t n_hay, const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
     size_t first, stride, count;
     am_shard_plan(n_hay, nslots, slot, &first, &stride, &count);
     if (count == 0) return AM_OK;
     std::vector<const void*> ptrs(count);
     std::vector<size_t> ln(count);
     for (size_t i = 0; i < count; ++i) { ptrs[i] = d_hays[first + i * stride]; ln[i] = lens[first + i * stride]; }
-    am_needle* h = sl.needle;
-    int rc = check_needle(h);
+    int rc = check_needle(sl.needle);
     if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
-    return match_many(h, ptrs.data(), ln.data(), count, p, out, cap_per_hay, n_out, 0, first, stride);
+    return slot_match(sl, job, ptrs.data(), ln.data(), count, p, out, cap, n_out, first, stride);
 }
 
 // host haystacks: a copier thread fills the two-slot ring one haystack ahead of the matcher
-int slot_run_host(am_pool::Slot& sl, size_t slot, size_t nslots, const float* const* hays, const size_t* lens, size_t n_hay,
-                  const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+int slot_run_host(am_pool::Slot& sl, const PoolJob& job, size_t slot, size_t nslots, const void* const* hays, const size_t* lens,
+                  size_t n_hay, const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
     size_t first, stride, count;
     am_shard_plan(n_hay, nslots, slot, &first, &stride, &count);
     if (count == 0) return AM_OK;
@@ -1671,14 +1807,14 @@ int slot_run_host(am_pool::Slot& sl, size_t slot, size_t nslots, const float* co
     if (rc) return rc;
     size_t max_len = 0;
     for (size_t i = 0; i < count; ++i) if (hays[first + i * stride]) max_len = std::max(max_len, lens[first + i * stride]);
-    if (max_len * sizeof(float) > sl.ring_cap) {
+    if (max_len * 4 > sl.ring_cap) {
         for (void*& r : sl.ring) { if (r) (void)hipFree(r); r = nullptr; }
         sl.ring_cap = 0;
         for (void*& r : sl.ring) {
-            hipError_t e = hipMalloc(&r, max_len * sizeof(float));
+            hipError_t e = hipMalloc(&r, max_len * 4);
             if (e != hipSuccess) { r = nullptr; return hip_fail(e, "hipMalloc(pool ring)"); }
         }
-        sl.ring_cap = max_len * sizeof(float);
+        sl.ring_cap = max_len * 4;
     }
     std::mutex m;
     std::condition_variable cv;
@@ -1697,7 +1833,7 @@ int slot_run_host(am_pool::Slot& sl, size_t slot, size_t nslots, const float* co
             const size_t k = first + i * stride;
             hipError_t e = hipSuccess;
             if (hays[k] && lens[k]) {
-                e = hipMemcpyAsync(sl.ring[b], hays[k], lens[k] * sizeof(float), hipMemcpyHostToDevice, sl.copy_stream);
+                e = hipMemcpyAsync(sl.ring[b], hays[k], lens[k] * 4, hipMemcpyHostToDevice, sl.copy_stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(sl.copy_stream);
             }
             std::lock_guard<std::mutex> lk(m);
@@ -1716,10 +1852,7 @@ int slot_run_host(am_pool::Slot& sl, size_t slot, size_t nslots, const float* co
         }
         const size_t k = first + i * stride;
         const void* src = (hays[k] && lens[k]) ? sl.ring[b] : nullptr;
-        {
-            std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
-            rc = match_many(h, &src, &lens[k], 1, p, out, cap_per_hay, n_out, 0, k, 1);
-        }
+        rc = slot_match(sl, job, &src, &lens[k], 1, p, out, cap, n_out, k, 1);
         {
             std::lock_guard<std::mutex> lk(m);
             ready[b] = false;
@@ -1734,20 +1867,24 @@ int slot_run_host(am_pool::Slot& sl, size_t slot, size_t nslots, const float* co
     return worst;
 }
 
-int pool_run(am_pool* pool, const float* const* hays, const size_t* lens, size_t n_hay, const am_match_params* p,
-             am_peak* out, size_t cap_per_hay, size_t* n_out, bool host) {
-    if (!pool || !hays || !lens || !p || !n_out || (!out && cap_per_hay)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+int pool_run(am_pool* pool, const PoolJob& job, const void* const* hays, const size_t* lens, size_t n_hay, const am_match_params* p,
+             am_peak* out, size_t cap, size_t* n_out, bool host) {
+    if (!pool || !hays || !lens || !p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (job.fmt != AM_FMT_F32_MONO && job.fmt != AM_FMT_S16_STEREO) return fail(AM_ERR_INVALID_ARG, "bad sample format");
     std::lock_guard<std::mutex> lk(pool->mu);
     const size_t nslots = pool->slots.size();
-    for (size_t k = 0; k < n_hay; ++k) n_out[k] = 0;
+    const size_t nn = pool->slots.empty() ? 0 : pool->slots[0].needles.size();
+    if (!job.multi && nn != 1)
+        return fail(AM_ERR_INVALID_ARG, "this pool holds several needles: use am_pool_match_multi_batch*");
+    for (size_t k = 0; k < n_hay * (job.multi ? nn : 1); ++k) n_out[k] = 0;
     if (n_hay == 0) return AM_OK;
     std::vector<int> rcs(nslots, AM_OK);
     std::vector<std::string> errs(nslots);
     std::vector<std::thread> threads;
     for (size_t s = 0; s < nslots; ++s)
         threads.emplace_back([&, s] {
-            rcs[s] = host ? slot_run_host(pool->slots[s], s, nslots, hays, lens, n_hay, p, out, cap_per_hay, n_out)
-                          : slot_run_device(pool->slots[s], s, nslots, hays, lens, n_hay, p, out, cap_per_hay, n_out);
+            rcs[s] = host ? slot_run_host(pool->slots[s], job, s, nslots, hays, lens, n_hay, p, out, cap, n_out)
+                          : slot_run_device(pool->slots[s], job, s, nslots, hays, lens, n_hay, p, out, cap, n_out);
             if (rcs[s]) errs[s] = t_err;   // the error string is thread-local: hand it to the caller's thread
         });
     for (std::thread& th : threads) th.join();
@@ -1763,12 +1900,38 @@ int pool_run(am_pool* pool, const float* const* hays, const size_t* lens, size_t
 
 int am_pool_match_batch(am_pool* pool, const float* const* haystacks, const size_t* lens, size_t n_hay,
                         const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
-    return pool_run(pool, haystacks, lens, n_hay, p, out, cap_per_hay, n_out, true);
+    return pool_run(pool, PoolJob{false, AM_FMT_F32_MONO}, reinterpret_cast<const void* const*>(haystacks), lens, n_hay, p, out, cap_per_hay, n_out, true);
 }
 
 int am_pool_match_batch_device(am_pool* pool, const float* const* d_haystacks, const size_t* lens, size_t n_hay,
                                const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
-    return pool_run(pool, d_haystacks, lens, n_hay, p, out, cap_per_hay, n_out, false);
+    return pool_run(pool, PoolJob{false, AM_FMT_F32_MONO}, reinterpret_cast<const void* const*>(d_haystacks), lens, n_hay, p, out, cap_per_hay, n_out, false);
+}
+
+int am_pool_match_batch_pcm16(am_pool* pool, const int16_t* const* interleaved, const size_t* frames, size_t n_hay,
+                              const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    return pool_run(pool, PoolJob{false, AM_FMT_S16_STEREO}, reinterpret_cast<const void* const*>(interleaved), frames, n_hay, p, out, cap_per_hay, n_out, true);
+}
+
+int am_pool_match_batch_pcm16_device(am_pool* pool, const int16_t* const* d_interleaved, const size_t* frames, size_t n_hay,
+                                     const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out) {
+    return pool_run(pool, PoolJob{false, AM_FMT_S16_STEREO}, reinterpret_cast<const void* const*>(d_interleaved), frames, n_hay, p, out, cap_per_hay, n_out, false);
+}
+
+int am_pool_match_multi_batch(am_pool* pool, const void* const* haystacks, const size_t* lens, size_t n_hay, int sample_format,
+                              const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out) {
+    return pool_run(pool, PoolJob{true, sample_format}, haystacks, lens, n_hay, p, out, cap_per_pair, n_out, true);
+}
+
+int am_pool_match_multi_batch_device(am_pool* pool, const void* const* d_haystacks, const size_t* lens, size_t n_hay, int sample_format,
+                                     const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out) {
+    return pool_run(pool, PoolJob{true, sample_format}, d_haystacks, lens, n_hay, p, out, cap_per_pair, n_out, false);
+}
+
+int am_pool_needle_count(const am_pool* pool, size_t* n_needles) {
+    if (!pool || !n_needles) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    *n_needles = pool->slots.empty() ? 0 : pool->slots[0].needles.size();
+    return AM_OK;
 }
 
 int am_set_progress_callback(am_progress_fn fn, void* user) {

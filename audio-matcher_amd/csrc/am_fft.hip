@@ -675,7 +675,7 @@ __device__ __forceinline__ void k2_multiply_fetch(const float2 (&z)[32], __amdgp
 }
 
 // inverse passes 3, 2, 1 of the product q and the row store
-template <bool HALF>
+template <bool HALF, int SAUX = AM_K2_STORE_AUX>
 __device__ __forceinline__ void k2_inverse(const K2Lane& k, float2 (&q)[32], float4* lds4, __amdgpu_buffer_rsrc_t rdst) {
     const int t = k.t, hi = k.hi, cp = k.cp;
     // ---- inverse pass 3 over c' ----
@@ -722,7 +722,7 @@ __device__ __forceinline__ void k2_inverse(const K2Lane& k, float2 (&q)[32], flo
     }
 #pragma unroll
     for (int a = 0; a < 16; ++a)
-        buf_store4<AM_K2_STORE_AUX>(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+        buf_store4<SAUX>(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
                                                        x1[brev<16>(a)].x, x1[brev<16>(a)].y));
 }
 
@@ -918,6 +918,12 @@ hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n
 // multiplies that spectrum with its own and runs its own inverse transform into its
 // own work matrix.  Per needle the row costs 8/n + 8 bytes of HBM traffic instead of
 // 16 and the forward half of the arithmetic is shared.
+#ifndef AM_K2G_PREFETCH
+#define AM_K2G_PREFETCH 1    // request the first quarter of the next needle's spectrum row one needle ahead
+#endif
+#ifndef AM_K2G_STORE_AUX
+#define AM_K2G_STORE_AUX 0   // cache policy of the eight write streams (2 = nt)
+#endif
 __global__ void __launch_bounds__(256, 2)
 k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsigned npairs) {
     extern __shared__ float4 lds4[];
@@ -933,10 +939,11 @@ k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsi
     // the first quarter of a needle's spectrum row is requested one needle ahead, so
     // that its latency hides behind the previous needle's inverse passes
     float4 hq[4];
-    k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[0]) + hoff4, kN2 * 8), k.voff, 0, hq);
+    if (AM_K2G_PREFETCH) k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[0]) + hoff4, kN2 * 8), k.voff, 0, hq);
 #pragma unroll 1
     for (int j = 0; j < grp.n; ++j) {
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(grp.hc[j]) + hoff4, kN2 * 8);
+        if (!AM_K2G_PREFETCH) k2_fetch_quarter(rh, k.voff, 0, hq);
         // The twiddle powers of the inverse passes depend on the lane only; left alone
         // the compiler computes them once before the loop and keeps ~120 values alive
         // across it (in scratch).  Recomputing them per needle is far cheaper.
@@ -945,10 +952,12 @@ k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsi
                           "+v"(kj.wc0.x), "+v"(kj.wc0.y), "+v"(kj.wc1.x), "+v"(kj.wc1.y));
         float2 q[32];
         k2_multiply_fetch(z, rh, k.voff, hq, q);
-        const int jn = j + 1 < grp.n ? j + 1 : j;   // (the last needle refetches its own quarter: harmless)
-        k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[jn]) + hoff4, kN2 * 8), k.voff, 0, hq);
-        __builtin_amdgcn_sched_barrier(0);
-        k2_inverse<false>(kj, q, lds4, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
+        if (AM_K2G_PREFETCH) {
+            const int jn = j + 1 < grp.n ? j + 1 : j;   // (the last needle refetches its own quarter: harmless)
+            k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[jn]) + hoff4, kN2 * 8), k.voff, 0, hq);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        k2_inverse<false, AM_K2G_STORE_AUX>(kj, q, lds4, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
         __syncthreads();   // the last pass read rows of every wave: finish before the next needle overwrites them
     }
 }

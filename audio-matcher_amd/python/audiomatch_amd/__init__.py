@@ -30,6 +30,11 @@ AM_OK, AM_ERR_INVALID_ARG, AM_ERR_CAPACITY, AM_ERR_HIP, AM_ERR_NO_DEVICE, \
 AM_MAX_PEAKS_PER_CHUNK = 1024
 
 
+class Fmt(enum.IntEnum):           # sample format of a haystack buffer (AM_FMT_*)
+    F32_MONO = 0
+    S16_STEREO = 1                 # interleaved i16 stereo frames (mp3_reader.rs:26-37)
+
+
 class Mode(enum.IntEnum):          # audio_matcher.rs:55-59
     Full = 0
     Same = 1
@@ -122,6 +127,24 @@ _SIGNATURES = {
     "am_pool_match_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
                                              C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
                                              C.POINTER(C.c_size_t)]),
+    "am_match_multi_batch_device": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                              C.c_size_t, C.c_int, C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                              C.POINTER(C.c_size_t)]),
+    "am_pool_match_batch_pcm16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                            C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                            C.POINTER(C.c_size_t)]),
+    "am_pool_match_batch_pcm16_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                                   C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                                   C.POINTER(C.c_size_t)]),
+    "am_pool_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.c_size_t,
+                                       C.POINTER(C.c_void_p)]),
+    "am_pool_needle_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "am_pool_match_multi_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
+                                            C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                            C.POINTER(C.c_size_t)]),
+    "am_pool_match_multi_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
+                                                   C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
+                                                   C.POINTER(C.c_size_t)]),
     "am_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "am_profile_reset": (C.c_int, [C.c_int]),
     "am_profile_query": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -441,6 +464,98 @@ class Pool:
         counts = (C.c_size_t * max(1, k))()
         _check(lib().am_pool_match_batch_device(self._p, arr_p, arr_l, k, C.byref(params), buf, cap_per_hay, counts))
         return _split_batch(buf, counts, k, cap_per_hay)
+
+    def match_batch_pcm16(self, haystacks, params: AmMatchParams, cap_per_hay: int = 256):
+        """Host haystacks as interleaved i16 stereo arrays (2 * frames values; None = skipped)."""
+        hs = [None if h is None else np.ascontiguousarray(h, dtype=np.int16) for h in haystacks]
+        k = len(hs)
+        arr_p = (C.c_void_p * k)(*[None if h is None else h.ctypes.data for h in hs])
+        arr_l = (C.c_size_t * k)(*[0 if h is None else h.size // 2 for h in hs])
+        buf = (AmPeak * max(1, cap_per_hay * k))()
+        counts = (C.c_size_t * max(1, k))()
+        _check(lib().am_pool_match_batch_pcm16(self._p, arr_p, arr_l, k, C.byref(params), buf, cap_per_hay, counts))
+        return _split_batch(buf, counts, k, cap_per_hay)
+
+    def match_batch_pcm16_device(self, ptrs, frames, params: AmMatchParams, cap_per_hay: int = 256):
+        k = len(ptrs)
+        arr_p = (C.c_void_p * k)(*ptrs)
+        arr_l = (C.c_size_t * k)(*frames)
+        buf = (AmPeak * max(1, cap_per_hay * k))()
+        counts = (C.c_size_t * max(1, k))()
+        _check(lib().am_pool_match_batch_pcm16_device(self._p, arr_p, arr_l, k, C.byref(params), buf, cap_per_hay, counts))
+        return _split_batch(buf, counts, k, cap_per_hay)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            lib().am_pool_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _split_pairs(buf, counts, n_hay: int, nn: int, cap: int):
+    """[k][j] = peaks of haystack k against needle j (slot k * nn + j)."""
+    return [[[Peak(int(b.start), int(b.end), float(b.height), float(b.prominence))
+              for b in buf[(k * nn + j) * cap: (k * nn + j) * cap + counts[k * nn + j]]] for j in range(nn)]
+            for k in range(n_hay)]
+
+
+def match_multi_batch_device(algos, ptrs, lengths, params: AmMatchParams, fmt: int = Fmt.F32_MONO, cap_per_pair: int = 64):
+    """Several equal-length needles against a batch of resident haystacks (am_match_multi_batch_device):
+    result [k][j] = haystack k against needle j."""
+    nn, k = len(algos), len(ptrs)
+    handles = (C.c_void_p * nn)(*[a._h for a in algos])
+    arr_p = (C.c_void_p * k)(*ptrs)
+    arr_l = (C.c_size_t * k)(*lengths)
+    buf = (AmPeak * max(1, cap_per_pair * k * nn))()
+    counts = (C.c_size_t * max(1, k * nn))()
+    _check(lib().am_match_multi_batch_device(handles, nn, arr_p, arr_l, k, int(fmt), C.byref(params), buf, cap_per_pair, counts))
+    return _split_pairs(buf, counts, k, nn, cap_per_pair)
+
+
+class MultiPool:
+    """Several equal-length needles replicated on every listed device (am_pool_create_multi): the file
+    loop of matcher::run around N snippets, haystack k on slot k mod n."""
+
+    def __init__(self, samples, devices=None):
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in samples]
+        assert arrs and all(a.size == arrs[0].size for a in arrs)
+        self._keep = arrs
+        self.n_needles = len(arrs)
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._p = C.c_void_p()
+        if devices is None:
+            _check(lib().am_pool_create_multi(ptrs, len(arrs), arrs[0].size, None, 0, C.byref(self._p)))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().am_pool_create_multi(ptrs, len(arrs), arrs[0].size, arr, len(devices), C.byref(self._p)))
+        n = C.c_size_t(0)
+        _check(lib().am_pool_size(self._p, C.byref(n)))
+        self.size = n.value
+
+    def _run(self, fn, ptrs, lens, fmt, params, cap_per_pair):
+        k, nn = len(ptrs), self.n_needles
+        arr_p = (C.c_void_p * max(1, k))(*ptrs)
+        arr_l = (C.c_size_t * max(1, k))(*lens)
+        buf = (AmPeak * max(1, cap_per_pair * k * nn))()
+        counts = (C.c_size_t * max(1, k * nn))()
+        _check(fn(self._p, arr_p, arr_l, k, int(fmt), C.byref(params), buf, cap_per_pair, counts))
+        return _split_pairs(buf, counts, k, nn, cap_per_pair)
+
+    def match_batch(self, haystacks, params: AmMatchParams, fmt: int = Fmt.F32_MONO, cap_per_pair: int = 64):
+        """Host haystacks: f32 arrays, or interleaved i16 stereo arrays with fmt = Fmt.S16_STEREO."""
+        dt = np.float32 if int(fmt) == Fmt.F32_MONO else np.int16
+        per = 1 if int(fmt) == Fmt.F32_MONO else 2
+        hs = [None if h is None else np.ascontiguousarray(h, dtype=dt) for h in haystacks]
+        return self._run(lib().am_pool_match_multi_batch, [None if h is None else h.ctypes.data for h in hs],
+                         [0 if h is None else h.size // per for h in hs], fmt, params, cap_per_pair)
+
+    def match_batch_device(self, ptrs, lengths, params: AmMatchParams, fmt: int = Fmt.F32_MONO, cap_per_pair: int = 64):
+        return self._run(lib().am_pool_match_multi_batch_device, ptrs, lengths, fmt, params, cap_per_pair)
 
     def close(self):
         if getattr(self, "_p", None):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AM_ABI_VERSION 2
+#define AM_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -48,6 +48,12 @@ enum { AM_MODE_FULL = 0, AM_MODE_SAME = 1, AM_MODE_VALID = 2 };
  *   AM_SCALE_MY  = MyConvolve: corr / sum(needle^2) / within.len()
  *                                                  audio_matcher.rs:442-448 */
 enum { AM_SCALE_NONE = 0, AM_SCALE_LIB = 1, AM_SCALE_MY = 2 };
+
+/* Sample format of a haystack buffer.  The reference decodes every file to interleaved 16-bit
+ * stereo (mp3_reader.rs:26 asserts two channels) and hands calc_chunks the down-mixed f32 mono
+ * stream (mp3_reader.rs:28-37); both ends of that step are accepted.  One element (an f32 sample,
+ * or one stereo frame of two i16) is 4 bytes in either format. */
+enum { AM_FMT_F32_MONO = 0, AM_FMT_S16_STEREO = 1 };
 
 /* Not a limit on results: any number of peaks may pass the prominence filter in a chunk and, as
  * find_peaks does, the library returns every one the distance filter keeps (the caller's `cap`
@@ -153,6 +159,19 @@ int am_match_batch_device(const am_needle* h, const float* const* d_haystacks, c
 int am_match_multi_device(const am_needle* const* needles, size_t n_needles, const float* d_haystack, size_t len,
                           const am_match_params* p, am_peak* out, size_t cap_per_needle, size_t* n_out);
 
+/* The per-file loop of matcher::run (matcher/mod.rs:42-87) around SEVERAL snippets (BASELINE
+ * config 4: "32 needles vs 1000 x 1 h haystacks, haystack FFT reused"): n_needles equal-length
+ * needles on one device against n_hay resident haystacks of `sample_format` (AM_FMT_*; lens in
+ * samples / frames).  Per haystack the forward column pass runs once and the forward row
+ * transforms once per group of needles; the peak pick of one (haystack, needle) pair runs beside the
+ * transforms of the next.  out holds cap_per_pair slots per pair, pair (haystack k, needle j) at
+ * index k * n_needles + j; n_out likewise.  Results equal n_hay * n_needles separate am_match_device /
+ * am_match_pcm16_device calls (offsets identical, heights and prominences to f32 rounding); a
+ * haystack with non-finite samples loses exactly the windows that hold them, as there. */
+int am_match_multi_batch_device(const am_needle* const* needles, size_t n_needles, const void* const* d_haystacks,
+                                const size_t* lens, size_t n_hay, int sample_format, const am_match_params* p,
+                                am_peak* out, size_t cap_per_pair, size_t* n_out);
+
 /* The same matcher on interleaved 16-bit stereo PCM, the sample format the
  * reference decodes to (mp3_reader.rs:26 asserts two channels): the down-mix
  * mono = (l as f32 + r as f32) * 0.5 * (1/65535) (mp3_reader.rs:12, 28-37) is
@@ -220,6 +239,25 @@ int am_pool_match_batch(am_pool* pool, const float* const* haystacks, const size
 /* Same with resident haystacks: d_haystacks[k] must live on the device of slot k mod n_dev. */
 int am_pool_match_batch_device(am_pool* pool, const float* const* d_haystacks, const size_t* lens, size_t n_hay,
                                const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
+
+/* The same two loops on interleaved 16-bit stereo PCM (what the reference decodes every file
+ * to, mp3_reader.rs:26-37); `frames` per haystack. */
+int am_pool_match_batch_pcm16(am_pool* pool, const int16_t* const* interleaved, const size_t* frames, size_t n_hay,
+                              const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
+int am_pool_match_batch_pcm16_device(am_pool* pool, const int16_t* const* d_interleaved, const size_t* frames, size_t n_hay,
+                                     const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
+/* A pool of SEVERAL equal-length needles (BASELINE config 4 over every GPU of the node): each
+ * needle = one LibConvolve::new (audio_matcher.rs:289), replicated per device.  The single-needle
+ * calls above refuse such a pool; am_pool_match_multi_batch* run am_match_multi_batch_device per
+ * slot on that slot's shard (haystack k on slot k mod n_dev), host buffers through the same
+ * two-slot copy ring.  out / n_out: cap_per_pair slots per (haystack, needle) pair at index
+ * k * n_needles + j, k the index in the caller's batch. */
+int am_pool_create_multi(const float* const* needles, size_t n_needles, size_t n, const int* devices, size_t n_dev, am_pool** out);
+int am_pool_needle_count(const am_pool* pool, size_t* n_needles);
+int am_pool_match_multi_batch(am_pool* pool, const void* const* haystacks, const size_t* lens, size_t n_hay, int sample_format,
+                              const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out);
+int am_pool_match_multi_batch_device(am_pool* pool, const void* const* d_haystacks, const size_t* lens, size_t n_hay, int sample_format,
+                                     const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out);
 
 /* ---- progress hooks ---------------------------------------------------------- */
 /* The two-stage progress callbacks of calc_chunks (audio_matcher.rs:102-117, 129:

@@ -176,8 +176,77 @@ public:
         return out;
     }
 
+    // the same loop on interleaved i16 stereo frames, the format the reference decodes to
+    // (mp3_reader.rs:26-37); lens in frames
+    std::vector<std::vector<Peak>> calc_chunks_pcm16(std::uint16_t sr, const std::vector<const std::int16_t*>& haystacks,
+                                                     const std::vector<std::size_t>& frames, bool scale, const Config& config,
+                                                     std::size_t cap_per_haystack = 256) {
+        const am_match_params p = config.params(sr, scale);
+        const std::size_t k = haystacks.size();
+        std::vector<am_peak> buf(k * cap_per_haystack);
+        std::vector<std::size_t> n(k, 0);
+        int rc = am_pool_match_batch_pcm16(p_, haystacks.data(), frames.data(), k, &p, buf.data(), cap_per_haystack, n.data());
+        if (rc == AM_ERR_CAPACITY) {
+            for (std::size_t v : n) cap_per_haystack = std::max(cap_per_haystack, v);
+            buf.assign(k * cap_per_haystack, am_peak{});
+            rc = am_pool_match_batch_pcm16(p_, haystacks.data(), frames.data(), k, &p, buf.data(), cap_per_haystack, n.data());
+        }
+        check(rc);
+        std::vector<std::vector<Peak>> out(k);
+        for (std::size_t i = 0; i < k; ++i)
+            for (std::size_t j = 0; j < n[i]; ++j) {
+                const am_peak& q = buf[i * cap_per_haystack + j];
+                out[i].push_back(Peak{static_cast<std::size_t>(q.start), static_cast<std::size_t>(q.end), q.height, q.prominence});
+            }
+        return out;
+    }
+
 private:
     am_pool* p_ = nullptr;
+};
+
+// matcher::run's file loop around SEVERAL snippets (BASELINE config 4) over every GPU: all needles
+// replicated per device, the haystack's forward transform shared by the needles of a group.
+class HipConvolveMultiPool {
+public:
+    HipConvolveMultiPool(const std::vector<std::vector<float>>& samples, const std::vector<int>& devices = {}) {
+        std::vector<const float*> ptrs;
+        for (const auto& v : samples) ptrs.push_back(v.data());
+        check(am_pool_create_multi(ptrs.data(), ptrs.size(), samples.empty() ? 0 : samples[0].size(),
+                                   devices.empty() ? nullptr : devices.data(), devices.size(), &p_));
+        nn_ = samples.size();
+    }
+    HipConvolveMultiPool(const HipConvolveMultiPool&) = delete;
+    HipConvolveMultiPool& operator=(const HipConvolveMultiPool&) = delete;
+    ~HipConvolveMultiPool() { am_pool_destroy(p_); }
+    // result [k][j]: haystack k against needle j; haystacks are host buffers of `sample_format`
+    std::vector<std::vector<std::vector<Peak>>> calc_chunks(std::uint16_t sr, const std::vector<const void*>& haystacks,
+                                                            const std::vector<std::size_t>& lens, int sample_format, bool scale,
+                                                            const Config& config, std::size_t cap_per_pair = 64) {
+        const am_match_params p = config.params(sr, scale);
+        const std::size_t k = haystacks.size();
+        std::vector<am_peak> buf(k * nn_ * cap_per_pair);
+        std::vector<std::size_t> n(k * nn_, 0);
+        int rc = am_pool_match_multi_batch(p_, haystacks.data(), lens.data(), k, sample_format, &p, buf.data(), cap_per_pair, n.data());
+        if (rc == AM_ERR_CAPACITY) {
+            for (std::size_t v : n) cap_per_pair = std::max(cap_per_pair, v);
+            buf.assign(k * nn_ * cap_per_pair, am_peak{});
+            rc = am_pool_match_multi_batch(p_, haystacks.data(), lens.data(), k, sample_format, &p, buf.data(), cap_per_pair, n.data());
+        }
+        check(rc);
+        std::vector<std::vector<std::vector<Peak>>> out(k, std::vector<std::vector<Peak>>(nn_));
+        for (std::size_t i = 0; i < k; ++i)
+            for (std::size_t j = 0; j < nn_; ++j)
+                for (std::size_t q = 0; q < n[i * nn_ + j]; ++q) {
+                    const am_peak& v = buf[(i * nn_ + j) * cap_per_pair + q];
+                    out[i][j].push_back(Peak{static_cast<std::size_t>(v.start), static_cast<std::size_t>(v.end), v.height, v.prominence});
+                }
+        return out;
+    }
+
+private:
+    am_pool* p_ = nullptr;
+    std::size_t nn_ = 0;
 };
 
 }  // namespace audiomatch

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(amlib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", amlib.LIB_PATH], text=True)
     exported = set(re.findall(r"\bT (am_[a-z0-9_]+)\b", out))
     assert set(header_symbols()) <= exported
-    assert amlib.lib().am_abi_version() == 2
+    assert amlib.lib().am_abi_version() == 3
 
 
 def test_header_cites_reference_for_every_entry_point():

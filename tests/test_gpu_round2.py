@@ -76,21 +76,33 @@ def test_k3_truth_table_pairs_through_am_match(gpu):
     assert [g.start for g in algo.match(same, p)] == [1, 3]
 
 
+# measured on MI355X (profiles/r03/k1_kat.txt); the asserted bounds leave a factor of about two
+K1_KAT_BOUNDS = {"direct": 1.2e-5, 10: 1.2e-5, 21: 1.2e-5, 22: 1.2e-5}
+
+
 def test_k1_known_answer_at_reference_tolerance(gpu):
-    """audio_matcher.rs:490-517 at the reference's own bound (abs diff < 1.2e-5, :511): tiny
-    needles are summed directly, which is exact on this integer data.  The transform path on
-    the same input (forced 2^10 plan) is reported and held to the same bound relative to the
-    data's magnitude (its values reach 52; ten f32 butterfly stages)."""
+    """audio_matcher.rs:490-517 at the reference's own ABSOLUTE bound (|diff| < 1.2e-5, :511, on
+    values up to 52) -- on the path the library picks for this input (direct summation: exact on
+    integer data) and, with the plan forced, on the transform kernels themselves: the generic 2^10
+    plan and both register plans (2^21 = 256 x 8192, 2^22 = 512 x 8192; the 20 samples zero-padded
+    into one block).  The measured errors go to gpurun_out/k1_kat.txt and into the failure text."""
+    import os
     within = np.arange(-10, 10, dtype=np.float32)
     expect = np.array([6 * j - 52 for j in range(18)], dtype=np.float32)
     algo = gpu.HipConvolve([1.0, 2.0, 3.0])
-    got = algo.correlate_with_sample(within, gpu.Mode.Valid, False)
-    assert np.abs(got - expect).max() < 1.2e-5
-    algo.set_option("log_n", 10)
-    fft = algo.correlate_with_sample(within, gpu.Mode.Valid, False)
-    err = float(np.abs(fft - expect).max())
-    print("K1 KAT: direct max err %.3g, 2^10 transform max err %.3g" % (float(np.abs(got - expect).max()), err))
-    assert err / np.abs(expect).max() < 1.2e-5
+    errs = {"direct": float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())}
+    for log_n in (10, 21, 22):
+        algo.set_option("log_n", log_n)
+        errs[log_n] = float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())
+    text = "K1 KAT (audio_matcher.rs:490-517), max |error| on values up to 52, reference bound 1.2e-5:\n" + \
+           "".join(f"  {'direct summation' if k == 'direct' else 'transform 2^%d' % k}: {v:.3e} (asserted < {K1_KAT_BOUNDS[k]:.1e})\n"
+                   for k, v in errs.items())
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "k1_kat.txt"), "w") as f:
+        f.write(text)
+    for k, v in errs.items():
+        assert v < K1_KAT_BOUNDS[k], text
 
 
 # ---------------------------------------------------------------------------

@@ -1,0 +1,310 @@
+"""GPU tests of the round-3 boundary work, all through the C ABI:
+several needles x a batch of haystacks (am_match_multi_batch_device, BASELINE configs[3]), the
+multi-needle and the i16-stereo pools (am_pool_create_multi, am_pool_match_multi_batch*,
+am_pool_match_batch_pcm16*), and the non-finite-sample corner cases of the round-2 review."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def key(r):
+    return [(q.start, q.end, q.height, q.prominence) for q in r]
+
+
+def pos(r):
+    return [(q.start, q.end) for q in r]
+
+
+def assert_same(got, exp, tol=TOL):
+    assert [g.start for g in got] == [e[0] for e in exp]
+    assert [g.end for g in got] == [e[1] for e in exp]
+    for g, e in zip(got, exp):
+        assert abs(g.height - e[2]) < tol and abs(g.prominence - e[3]) < tol
+
+
+def assert_close_peaks(got, one, tol=2e-6):
+    """Same peaks as a separate single-needle call: positions identical, values to f32 rounding
+    (the needle-group row kernel places a few fused multiply-adds differently)."""
+    assert pos(got) == pos(one)
+    for g, o in zip(got, one):
+        assert abs(g.height - o.height) < tol and abs(g.prominence - o.prominence) < tol
+
+
+# ---------------------------------------------------------------------------
+# several needles x several haystacks
+# ---------------------------------------------------------------------------
+def multi_inputs(oracle, sr, n_needles=3):
+    """Ragged batch: a long haystack (register kernels), a short one (generic plan), one shorter
+    than the needle, an empty one, another long one; needle j planted at its own offsets."""
+    s = 3 * sr
+    needles = [oracle.synth_uniform(31, 200 + j, 0, s) for j in range(n_needles)]
+    lens = [170 * sr, 25 * sr, s - 5, 0, 95 * sr + 321]
+    plants = {0: {0: [12.0, 100.5], 1: [60.0], 2: []},
+              1: {0: [], 1: [20.25], 2: [5.0]},
+              4: {0: [33.0], 1: [], 2: [70.0, 88.0]}}
+    hays = []
+    for k, n in enumerate(lens):
+        h = oracle.synth_uniform(31, 1 + k, 0, n) if n else np.zeros(0, np.float32)
+        for j, ts in plants.get(k, {}).items():
+            if j < n_needles:
+                for t in ts:
+                    off = int(t * sr)
+                    h[off:off + s] += needles[j]
+        hays.append(h)
+    return needles, hays, plants
+
+
+def test_multi_batch_equals_single_calls_and_oracle(gpu, oracle):
+    """am_match_multi_batch_device (matcher::run's file loop around N snippets, matcher/mod.rs:42-87):
+    every (haystack, needle) pair equals the separate single-needle call -- positions identical,
+    values to f32 rounding -- and the checker; with and without the overlapped peak pick, for
+    every needle grouping, twice (dense first call, sparse afterwards)."""
+    sr = 16000
+    needles, hays, plants = multi_inputs(oracle, sr)
+    cfg = gpu.Config(chunk_size_s=30.0, overlap_length_s=3.0, distance_s=10.0, prominence=0.13)
+    p = cfg.params(sr, gpu.Scale.LIB)
+    algos = [gpu.HipConvolve(n) for n in needles]
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) if h.size else None for h in hays]
+    ptrs = [b.ptr if b else None for b in bufs]
+    lens = [h.size for h in hays]
+    singles = [[a.match_device(b.ptr, h.size, p) if b is not None else [] for a in algos] for b, h in zip(bufs, hays)]
+    for k, per in plants.items():
+        for j, ts in per.items():
+            assert [q.start for q in singles[k][j]] == [int(t * sr) for t in ts], (k, j)
+    exp = oracle.calc_chunks(sr, hays[0], needles[0], p.chunk, p.overlap, 0.13, p.min_distance, 10.0)
+    try:
+        for overlap in (1, 0):
+            gpu.set_option("batch_overlap", overlap)
+            for group in (8, 2, 1):
+                gpu.set_option("needle_group", group)
+                for _ in range(2):
+                    res = gpu.match_multi_batch_device(algos, ptrs, lens, p)
+                    assert len(res) == len(hays) and all(len(r) == len(algos) for r in res)
+                    for k in range(len(hays)):
+                        for j in range(len(algos)):
+                            assert_close_peaks(res[k][j], singles[k][j])
+                    assert_same(res[0][0], exp)
+    finally:
+        gpu.set_option("batch_overlap", 1)
+        gpu.set_option("needle_group", 8)
+    # one haystack through the batch entry point == am_match_multi_device
+    one = gpu.match_multi_device(algos, ptrs[0], lens[0], p)
+    assert [key(r) for r in one] == [key(r) for r in gpu.match_multi_batch_device(algos, ptrs[:1], lens[:1], p)[0]]
+    # capacity: counts are reported, AM_ERR_CAPACITY returned
+    nn, k = len(algos), len(hays)
+    handles = (C.c_void_p * nn)(*[a._h for a in algos])
+    counts = (C.c_size_t * (nn * k))()
+    rc = gpu.lib().am_match_multi_batch_device(handles, nn, (C.c_void_p * k)(*ptrs), (C.c_size_t * k)(*lens), k, 0, C.byref(p),
+                                               None, 0, counts)
+    assert rc == gpu.AM_ERR_CAPACITY
+    assert [counts[i * nn + j] for i in range(k) for j in range(nn)] == [len(singles[i][j]) for i in range(k) for j in range(nn)]
+    rc = gpu.lib().am_match_multi_batch_device(handles, nn, (C.c_void_p * k)(*ptrs), (C.c_size_t * k)(*lens), k, 7, C.byref(p),
+                                               None, 0, counts)
+    assert rc == gpu.AM_ERR_INVALID_ARG
+
+
+def test_multi_batch_pcm16_and_half_levels(gpu, oracle):
+    """The same loop on interleaved i16 stereo frames (mp3_reader.rs:26-37) -- BASELINE configs[3]
+    and [4] combined -- at every precision level: offsets of the separate calls."""
+    sr = 16000
+    rng = np.random.default_rng(3)
+    s = 2 * sr
+    needles_lr = [rng.integers(-9000, 9000, size=2 * s).astype(np.int16) for _ in range(2)]
+    hays_lr = []
+    plant = {0: {0: [11.0, 70.0], 1: [40.5]}, 1: {0: [], 1: [15.0]}}
+    for k, secs in enumerate((100, 36)):
+        h = rng.integers(-9000, 9000, size=2 * secs * sr).astype(np.int32)
+        for j, ts in plant[k].items():
+            for t in ts:
+                off = int(t * sr)
+                h[2 * off:2 * (off + s)] += needles_lr[j]
+        hays_lr.append(np.clip(h, -32768, 32767).astype(np.int16))
+    p = gpu.Config(chunk_size_s=20.0, overlap_length_s=2.0, distance_s=8.0, prominence=0.4).params(sr, gpu.Scale.LIB)
+    algos = [gpu.HipConvolve.from_pcm16(n) for n in needles_lr]
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in hays_lr]
+    frames = [h.size // 2 for h in hays_lr]
+    singles = [[a.match_pcm16_device(b.ptr, f, p) for a in algos] for b, f in zip(bufs, frames)]
+    for k, per in plant.items():
+        for j, ts in per.items():
+            assert [q.start for q in singles[k][j]] == [int(t * sr) for t in ts]
+    res = gpu.match_multi_batch_device(algos, [b.ptr for b in bufs], frames, p, fmt=gpu.Fmt.S16_STEREO)
+    for k in range(2):
+        for j in range(2):
+            assert_close_peaks(res[k][j], singles[k][j])
+    try:
+        for level in (1, 2):
+            gpu.set_option("half_pipeline", level)
+            res = gpu.match_multi_batch_device(algos, [b.ptr for b in bufs], frames, p, fmt=gpu.Fmt.S16_STEREO)
+            for k in range(2):
+                for j in range(2):
+                    assert pos(res[k][j]) == pos(singles[k][j])
+                    for g, o in zip(res[k][j], singles[k][j]):
+                        assert abs(g.height - o.height) < 2e-3
+    finally:
+        gpu.set_option("half_pipeline", 0)
+
+
+def test_multi_batch_non_finite_samples(gpu, oracle):
+    """A NaN in one haystack of a several-needle batch: exactly the windows that hold it lose their
+    peaks, for every needle, as in the reference (audio_matcher.rs:114-122) and in am_match_device;
+    the other haystacks of the batch are untouched and nothing sticks to the handles."""
+    sr = 8000
+    s = 2 * sr
+    needles = [oracle.synth_uniform(41, 10 + j, 0, s) for j in range(2)]
+    hay = oracle.synth_uniform(41, 1, 0, 100 * sr)
+    for j, ts in enumerate(((13, 35, 57, 81), (5, 33, 90))):
+        for t in ts:
+            hay[t * sr:t * sr + s] += needles[j]
+    bad = hay.copy()
+    bad[34 * sr] = np.nan          # windows 2 and 3 of 10 s chunks with 2 s of overlap
+    bad[34 * sr + 9] = -np.inf
+    p = gpu.Config(chunk_size_s=10.0, overlap_length_s=2.0, distance_s=5.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    algos = [gpu.HipConvolve(n) for n in needles]
+    exp_clean = [oracle.calc_chunks(sr, hay, n, p.chunk, p.overlap, 0.13, p.min_distance, 5.0) for n in needles]
+    exp_bad = [oracle.calc_chunks(sr, bad, n, p.chunk, p.overlap, 0.13, p.min_distance, 5.0) for n in needles]
+    assert [len(e) for e in exp_clean] == [4, 3] and [len(e) for e in exp_bad] == [3, 2]
+    bufs = [gpu.DeviceBuffer.from_numpy(0, x) for x in (hay, bad, hay)]
+    for _ in range(2):
+        res = gpu.match_multi_batch_device(algos, [b.ptr for b in bufs], [hay.size] * 3, p)
+        for k, exps in enumerate((exp_clean, exp_bad, exp_clean)):
+            for j in range(2):
+                assert_same(res[k][j], exps[j])
+    # the single-haystack form as well (match_multi had no non-finite handling)
+    res = gpu.match_multi_device(algos, bufs[1].ptr, hay.size, p)
+    for j in range(2):
+        assert_same(res[j], exp_bad[j])
+        assert_same(algos[j].match_device(bufs[0].ptr, hay.size, p), exp_clean[j])
+
+
+# ---------------------------------------------------------------------------
+# pools
+# ---------------------------------------------------------------------------
+def test_multi_pool_equals_multi_batch(gpu, oracle):
+    """am_pool_create_multi / am_pool_match_multi_batch*: one, two and three slots on device 0 give
+    the results of am_match_multi_batch_device bit for bit, from host and from resident buffers;
+    the single-needle pool calls refuse a pool of several needles."""
+    sr = 16000
+    needles, hays, _ = multi_inputs(oracle, sr)
+    p = gpu.Config(chunk_size_s=30.0, overlap_length_s=3.0, distance_s=10.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    algos = [gpu.HipConvolve(n) for n in needles]
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) if h.size else None for h in hays]
+    ptrs = [b.ptr if b else None for b in bufs]
+    lens = [h.size for h in hays]
+    gpu.match_multi_batch_device(algos, ptrs, lens, p)
+    ref = gpu.match_multi_batch_device(algos, ptrs, lens, p)
+    assert sum(len(r) for per in ref for r in per) == 8
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        pool = gpu.MultiPool(needles, devices)
+        assert pool.size == len(devices) and pool.n_needles == len(needles)
+        pool.match_batch_device(ptrs, lens, p)
+        for _ in range(2):
+            got = pool.match_batch_device(ptrs, lens, p)
+            assert [[key(r) for r in per] for per in got] == [[key(r) for r in per] for per in ref], devices
+            got = pool.match_batch(hays, p)                   # host buffers: ring + copier thread per slot
+            assert [[key(r) for r in per] for per in got] == [[key(r) for r in per] for per in ref], devices
+        assert pool.match_batch([], p) == []
+        k = len(hays)
+        counts = (C.c_size_t * k)()
+        rc = gpu.lib().am_pool_match_batch_device(pool._p, (C.c_void_p * k)(*ptrs), (C.c_size_t * k)(*lens), k, C.byref(p),
+                                                  None, 0, counts)
+        assert rc == gpu.AM_ERR_INVALID_ARG and b"several needles" in gpu.lib().am_last_error_string()
+        pool.close()
+    n = C.c_size_t(0)
+    one = gpu.Pool(needles[0], [0])
+    assert gpu.lib().am_pool_needle_count(one._p, C.byref(n)) == 0 and n.value == 1
+
+
+def test_pool_pcm16_equals_single_calls(gpu, oracle):
+    """am_pool_match_batch_pcm16 / _device: the file loop on the format the reference decodes to
+    (mp3_reader.rs:26-37), haystack k on slot k mod n: equal to am_match_pcm16 per haystack."""
+    sr = 16000
+    rng = np.random.default_rng(9)
+    s = 2 * sr
+    needle_lr = rng.integers(-9000, 9000, size=2 * s).astype(np.int16)
+    hays = []
+    for secs, ts in ((90, (10.0, 61.5)), (0, ()), (35, (20.0,)), (1, ()), (120, (5.0, 50.0, 110.0))):
+        h = rng.integers(-9000, 9000, size=2 * secs * sr).astype(np.int32)
+        for t in ts:
+            off = int(t * sr)
+            h[2 * off:2 * (off + s)] += needle_lr
+        hays.append(np.clip(h, -32768, 32767).astype(np.int16))
+    p = gpu.Config(chunk_size_s=20.0, overlap_length_s=2.0, distance_s=8.0, prominence=0.4).params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve.from_pcm16(needle_lr)
+    singles = [key(algo.match_pcm16(h, p)) if h.size else [] for h in hays]
+    assert [len(r) for r in singles] == [2, 0, 1, 0, 3]
+    mono = gpu.pcm_s16_stereo_to_mono(needle_lr)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        pool = gpu.Pool(mono, devices)
+        for _ in range(2):
+            assert [key(r) for r in pool.match_batch_pcm16(hays, p)] == singles, devices
+        bufs = [gpu.DeviceBuffer.from_numpy(0, h) if h.size else None for h in hays]
+        res = pool.match_batch_pcm16_device([b.ptr if b else None for b in bufs], [h.size // 2 for h in hays], p)
+        assert [key(r) for r in res] == singles, devices
+        pool.close()
+    # half_pipeline 2 (BASELINE configs[4]) through the pool: a process-wide default the pool's handles follow
+    try:
+        gpu.set_option("half_pipeline", 2)
+        pool = gpu.Pool(mono, [0, 0])
+        res = pool.match_batch_pcm16(hays, p)
+        assert [[(q[0], q[1]) for q in key(r)] for r in res] == [[(q[0], q[1]) for q in r] for r in singles]
+        pool.close()
+    finally:
+        gpu.set_option("half_pipeline", 0)
+
+
+# ---------------------------------------------------------------------------
+# non-finite samples: the two corner cases of the round-2 review
+# ---------------------------------------------------------------------------
+def slack_case(oracle, sr, secs, hop, n_fft, s, chunk, seed):
+    """A NaN in the samples a block pair READS beyond the ones its scores depend on (hop is rounded
+    down to a multiple of 1024, a block still loads N samples), and a plant whose lag is the
+    second-to-last score of a clean window that has to be correlated again."""
+    needle = oracle.synth_uniform(seed, 0, 0, s)
+    hay = oracle.synth_uniform(seed, 1, 0, secs * sr)
+    # pair 0 = blocks 0, 1 reads samples [0, hop + N); its scores [0, 2 hop) depend on [0, 2 hop + s - 1)
+    lo, hi = 2 * hop + s - 1, hop + n_fft
+    assert hi - lo > 100
+    nan_at = lo + 100
+    w_bad = [i for i in range(secs * sr // chunk + 1) if i * chunk <= nan_at < i * chunk + chunk + s]
+    clean_fed_by_pair0 = [i for i in range(w_bad[0]) if i * chunk < 2 * hop]
+    assert len(clean_fed_by_pair0) >= 2
+    plants = [clean_fed_by_pair0[0] * chunk + 3 * sr,
+              clean_fed_by_pair0[-1] * chunk + chunk - 1,            # second-to-last score of that window
+              (w_bad[-1] + 2) * chunk + 4 * sr]
+    for t in plants:
+        hay[t:t + s] += needle
+    bad = hay.copy()
+    bad[nan_at] = np.nan
+    return needle, hay, bad, plants
+
+
+@pytest.mark.parametrize("plan", ["generic_2^17", "register_2^21"])
+def test_nan_in_the_rounding_slack_and_peak_at_window_end(gpu, oracle, plan):
+    """(a) classify_nonfinite must use the sample range K1 actually reads, (b) a
+    window that is correlated again keeps its LAST score (a peak at the second-to-last one stays a
+    peak).  Expected result: the checker's, window by window (audio_matcher.rs:114-124)."""
+    sr = 8000
+    s = 2 * sr
+    chunk = 10 * sr
+    if plan == "generic_2^17":
+        log_n, secs = 17, 100
+    else:
+        log_n, secs = 21, 560
+    n_fft = 1 << log_n
+    hop = (n_fft - s + 1) // 1024 * 1024
+    needle, hay, bad, plants = slack_case(oracle, sr, secs, hop, n_fft, s, chunk, 51)
+    p = gpu.Config(chunk_size_s=10.0, overlap_length_s=2.0, distance_s=5.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    assert p.chunk == chunk and p.overlap == s
+    algo = gpu.HipConvolve(needle)
+    algo.set_option("log_n", log_n)
+    exp_clean = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+    exp_bad = oracle.calc_chunks(sr, bad, needle, p.chunk, p.overlap, 0.13, p.min_distance, 5.0)
+    assert [e[0] for e in exp_clean] == plants and [e[0] for e in exp_bad] == plants
+    for _ in range(2):
+        assert_same(algo.match(bad, p), exp_bad)
+    assert_same(algo.match(hay, p), exp_clean)

@@ -10,8 +10,10 @@ import audiomatch_amd as am
 
 dev = 0
 SR = 44100; s = 10 * SR; h = 3600 * SR
-nn = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-groups = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+lean = "--lean" in sys.argv          # a few calls only (under rocprofv3 --pmc every kernel runs serialised)
+argv = [a for a in sys.argv if a != "--lean"]
+nn = int(argv[1]) if len(argv) > 1 else 8
+groups = [int(x) for x in argv[2].split(",")] if len(argv) > 2 else [1, 2, 4, 8]
 cfg = am.Config(chunk_size_s=60, overlap_length_s=10, distance_s=480.0, prominence=0.13)
 p = cfg.params(SR, am.Scale.LIB)
 needles = [am.synth_uniform_device(dev, s, 1, 2001 + k) for k in range(nn)]
@@ -24,10 +26,10 @@ out = {}
 KN = ("k1_cols_fwd", "k2_rows", "k3_cols_inv", "tile_stats", "peaks")
 for g in groups:
     am.set_option("needle_group", g)
-    for _ in range(12):
+    for _ in range(2 if lean else 12):
         res = am.match_multi_device(algos, hay.ptr, h, p)     # clock ramp + sparse-score state
     assert all([q.start for q in r] == [310 * SR + 1000 * k, 2010 * SR + 999 * k] for k, r in enumerate(res))
-    reps = 20
+    reps = 2 if lean else 20
     t0 = time.perf_counter()
     for _ in range(reps):
         am.match_multi_device(algos, hay.ptr, h, p)
