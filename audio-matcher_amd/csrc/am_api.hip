@@ -277,10 +277,6 @@ struct am_needle {
     float inv_autocorr = 0.f;
     std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
     std::map<int, unsigned*> spectra16;   // logN -> the same as scaled __half2 points (half_pipeline = 2)
-    // lowest chunk minimum of the scores seen so far (index 0: unscaled, 1: AM_SCALE_LIB);
-    // drives the raw-score write threshold of the fused scan
-    bool have_min[2] = {false, false};
-    float min_seg_min[2] = {0.f, 0.f};
     // per-handle overrides of the process-wide option defaults (-1 = follow the default)
     long long opt_log_n = -1, opt_half = -1;
 };
@@ -383,7 +379,7 @@ static int needle_spectrum16(am_needle* h, const Plan* pl, float hscale, const f
 // When a ScanRequest is given and the plan supports it, K3 also writes the level-0
 // (min,max) summary into the chosen set's stats32 and `fused` becomes true.
 struct ScanRequest {
-    float theta;             // in: raw-score write threshold
+    float margin;            // in: a run's raw scores are written when its maximum reaches its K3 tile's minimum + margin; < 0: all
     long long seg_c, seg_d;  // in: chunk geometry (scores i*seg_c .. i*seg_c + seg_d)
     int set;                 // in: which set of score-side buffers (0, or 1 in an overlapped batch)
     hipEvent_t before_k3;    // in: K3 must not overwrite that set before this event (or null)
@@ -431,6 +427,26 @@ static HalfScale half_scale(const am_needle* h, const Opts& o, const PlanDev& pl
     return s;
 }
 
+// Layout of a set's sparse-score side buffer: one byte per 32-score run (was it written?), then the
+// write thresholds K3 used, one float per (block, column tile).
+static size_t sparse_flag_bytes(long long out_count) { return ((size_t)((out_count + 31) / 32) + 255) / 256 * 256; }
+static size_t sparse_bytes(long long out_count, long long nblocks, int logN2) {
+    return sparse_flag_bytes(out_count) + sizeof(float) * ((size_t)nblocks << (logN2 - kColsLog));
+}
+static void fill_scan_cfg(ScanCfg* cfg, void* stats32, void* side, long long out_count, float margin, long long seg_c, long long seg_d) {
+    cfg->stats32 = static_cast<float2*>(stats32);
+    cfg->wflags = static_cast<unsigned char*>(side);
+    cfg->tile_theta = reinterpret_cast<float*>(static_cast<char*>(side) + sparse_flag_bytes(out_count));
+    cfg->margin = margin;
+    cfg->seg_c = seg_c; cfg->seg_d = seg_d;
+    cfg->inv_c = seg_c > 0 ? 1.0 / (double)seg_c : 0.0;
+}
+// what the peak pick sees of it: with every run written (margin < 0) it needs neither flags nor thresholds
+static SparseScores sparse_view(const ScanCfg& cfg, long long hop, int logN2) {
+    if (cfg.margin < 0.0f) return SparseScores{nullptr, cfg.stats32, nullptr, (int)hop, logN2};
+    return SparseScores{cfg.wflags, cfg.stats32, cfg.tile_theta, (int)hop, logN2};
+}
+
 static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
                            ScanRequest* scan_req = nullptr, int src_kind = 0) {
@@ -439,7 +455,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         // tiny needle: direct summation, every score written, no fused scan
         if (scan_req) {
             scan_req->fused = false;
-            scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
+            scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, 1, 5};
         }
         Job job{};
         job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
@@ -462,20 +478,15 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
-        scan_req->sparse = SparseScores{nullptr, nullptr, 0.f, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+        scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, (int)hop, pl->dev.logN2};
         if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
             DevBuf& b32 = scan_req->set ? c->stats32_b : c->stats32;
             DevBuf& bwf = scan_req->set ? c->wflags_b : c->wflags;
             if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-            if ((rc = bwf.ensure((size_t)nblocks << (pl->dev.logN2 - kColsLog)))) return rc;
-            scan.stats32 = (float2*)b32.p;
-            scan.wflags = (unsigned char*)bwf.p;
-            scan.theta = scan_req->theta;
-            scan.seg_c = scan_req->seg_c;
-            scan.seg_d = scan_req->seg_d;
-            scan.inv_c = scan.seg_c > 0 ? 1.0 / (double)scan.seg_c : 0.0;
+            if ((rc = bwf.ensure(sparse_bytes(out_count, nblocks, pl->dev.logN2)))) return rc;
+            fill_scan_cfg(&scan, b32.p, bwf.p, out_count, scan_req->margin, scan_req->seg_c, scan_req->seg_d);
             scan_req->fused = true;
-            scan_req->sparse = SparseScores{scan.wflags, scan.stats32, scan.theta, (int)hop, pl->dev.logN2, 1.0 / (double)hop};
+            scan_req->sparse = sparse_view(scan, hop, pl->dev.logN2);
         }
     }
     // half-precision storage of the work matrix: K2 normalises by the needle
@@ -591,7 +602,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     DevBuf& bstats = set ? c->stats_b : c->stats;
     DevBuf& bpeaks = set ? c->peaks_b : c->peaks;
     const float2* d_stats32 = (scan && scan->fused) ? scan->sparse.stats32 : nullptr;
-    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5};
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;
@@ -635,7 +646,7 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
                           std::vector<am_peak>& all) {
     const long long a = sg.a, b = std::min(sg.b, n_scores);
     if (b - a >= 0xFFFFFFFFll) return fail(AM_ERR_PEAK_OVERFLOW, "chunk of 2^32 scores or more with more than AM_MAX_PEAKS_PER_CHUNK peaks");
-    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, 0.f, 1, 5, 1.0};
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5};
     int rc;
     if ((rc = c->wide_ctl.ensure(24))) return rc;
     struct Ctl { unsigned long long best; int state; unsigned count; float seg_min; int ntiles; } ctl{0ull, 7, 0u, seg_min, -1};   // (state: handed over, head and tail pieces to be scanned)
@@ -802,14 +813,14 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     const bool my = p->scale == AM_SCALE_MY;
     const size_t window = (size_t)(p->chunk + p->overlap);
     const float factor = scale_factor(h, p->scale, window);
-    // Raw scores are written only where some score >= theta.  theta sits half a
-    // prominence above the lowest chunk minimum seen with this needle; the first
-    // call (no history) writes everything.  The peak kernel certifies per chunk
-    // that theta was low enough; a chunk that fails is redone with theta = -inf.
-    const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
-    const bool sparse_ok = !my && !o.dense && h->have_min[sm] && p->min_prominence > 0.f;
+    // Raw scores are written only for the 32-score runs whose maximum reaches their K3 tile's write
+    // threshold: the tile's own minimum in the block plus half a prominence (am_fft.hip, k3_finish).
+    // The peak kernel certifies per chunk that every threshold was low enough; a chunk that fails
+    // (a dip deeper than half a prominence that most tiles' samples missed) is redone with every
+    // run written.
+    const bool sparse_ok = !my && !o.dense && p->min_prominence > 0.f;
     ScanRequest scan{};
-    scan.theta = sparse_ok ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+    scan.margin = sparse_ok ? 0.5f * p->min_prominence : -1.0f;
     scan.seg_c = (long long)p->chunk;
     scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
     // main-pass segments of every haystack, back to back; MyConvolve scaling keeps the
@@ -921,9 +932,6 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         const int s0 = seg_off[k], s1 = seg_off[k + 1];
         if (n_chunks[k] == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
-        for (int i = s0; i < s1 && !h_bad[k]; ++i) {   // (a haystack with non-finite scores teaches the threshold nothing)
-            if (!my && (!h->have_min[sm] || h_hdr[i].seg_min < h->min_seg_min[sm])) { h->min_seg_min[sm] = h_hdr[i].seg_min; h->have_min[sm] = true; }
-        }
         all.clear();
         // Non-finite samples (NaN, +-inf; f32 sources only).  The reference transforms every window
         // on its own (audio_matcher.rs:114-122): a window that holds such a sample gets NaN scores
@@ -944,7 +952,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                 const Segment sg = segs[i];
                 const long long cnt = sg.b - sg.a;
                 ScanRequest one{};
-                one.theta = -FLT_MAX;
+                one.margin = -1.0f;
                 PeakArena own{};
                 if ((rc = c->spill.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
                 AM_HIP(hipMemsetAsync(c->arena_cur.p, 0, sizeof(unsigned), c->stream));
@@ -965,14 +973,14 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                 continue;
             }
             if (!(h_hdr[i].overflow & 7)) { append_header_peaks(h_hdr[i], arena, all); continue; }
-            // Rare: theta was too high for this chunk (its minimum lies further below the lowest
-            // minimum seen so far than half a prominence), its list found no room in the spill
+            // Rare: a write threshold was too high for this chunk (its minimum lies more than half a
+            // prominence below the minimum some K3 tile sampled), its list found no room in the spill
             // arena, or more than AM_MAX_PEAKS_PER_CHUNK peaks passed the prominence filter (the
-            // score buffers have moved on to later haystacks by now).  Redo the blocks that produce this chunk's scores with theta = -inf, in place
-            // in set 0 (same block layout, hence bit-identical scores), and pick the chunk again
-            // with a spill arena of its own.
+            // score buffers have moved on to later haystacks by now).  Redo the blocks that produce this
+            // chunk's scores with every run written, in place in set 0 (same block layout, hence
+            // bit-identical scores), and pick the chunk again with a spill arena of its own.
             ScanRequest full = scan;
-            full.theta = -FLT_MAX;
+            full.margin = -1.0f;
             full.range_a = segs[i].a; full.range_b = segs[i].b;
             PeakArena own{};
             if ((rc = c->spill.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
@@ -985,7 +993,6 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                                   (long long)p->min_distance, &full, spare_hdr, own))) return rc;
             AM_HIP(hipStreamSynchronize(c->stream));
             const SegHeader& hd = h_hdr[spare_hdr];
-            if (!my && hd.seg_min < h->min_seg_min[sm]) h->min_seg_min[sm] = hd.seg_min;
             if (hd.overflow & 1) {
                 if ((rc = pick_chunk_big(c, (const float*)c->scores.p, out_count, i, segs[i], p->min_prominence,
                                          (long long)p->min_distance, &full, hd.seg_min, all))) return rc;
@@ -996,7 +1003,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             const Segment sg = tail_segs[i];
             const long long cnt = sg.b - sg.a;
             ScanRequest one{};
-            one.theta = -FLT_MAX;
+            one.margin = -1.0f;
             one.seg_c = 0; one.seg_d = 0;
             PeakArena own{};
             if ((rc = c->spill.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
@@ -1053,7 +1060,6 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         return fail(AM_ERR_INVALID_ARG, "am_match_multi supports AM_SCALE_NONE and AM_SCALE_LIB");
     for (size_t k = 0; k < n_hay; ++k)
         for (size_t j = 0; j < nn; ++j) n_out[G(k) * nn + j] = 0;
-    const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
     // the chunk lists of every haystack, back to back, and each haystack's block layout
     std::vector<Segment> segs;
     std::vector<int> seg_off(n_hay + 1, 0);
@@ -1073,7 +1079,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         max_segs = std::max(max_segs, ns);
         max_work = std::max(max_work, matrix);
         max_matrix = std::max(max_matrix, matrix);
-        max_wflags = std::max(max_wflags, (size_t)geo[k].nblocks << 8);   // (at most 2^13 / 32 column tiles per block)
+        max_wflags = std::max(max_wflags, sparse_bytes(out_count, geo[k].nblocks, 13));   // (at most 2^13 / 32 column tiles per block)
     }
     seg_off[n_hay] = (int)segs.size();
     const size_t nsegs = segs.size();
@@ -1154,19 +1160,17 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             job.dst = d_scores;
             ScanRequest scan{};
             scan.set = set;
-            scan.theta = (!o.dense && h->have_min[sm] && p->min_prominence > 0.f) ? h->min_seg_min[sm] + 0.5f * p->min_prominence : -FLT_MAX;
+            scan.margin = (!o.dense && p->min_prominence > 0.f) ? 0.5f * p->min_prominence : -1.0f;
             scan.seg_c = (long long)p->chunk;
             scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
             scan.bad = src_kind == 0 ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
             scan.fused = fused;
-            scan.sparse = SparseScores{nullptr, nullptr, 0.f, (int)g.hop, pl->dev.logN2, 1.0 / (double)g.hop};
+            scan.sparse = SparseScores{nullptr, nullptr, nullptr, (int)g.hop, pl->dev.logN2};
             ScanCfg cfg{};
             if (fused) {
-                cfg.stats32 = (float2*)(set ? c->stats32_b.p : c->stats32.p);
-                cfg.wflags = (unsigned char*)(set ? c->wflags_b.p : c->wflags.p);
-                cfg.theta = scan.theta;
-                cfg.seg_c = scan.seg_c; cfg.seg_d = scan.seg_d; cfg.inv_c = 1.0 / (double)scan.seg_c;
-                scan.sparse = SparseScores{cfg.wflags, cfg.stats32, cfg.theta, (int)g.hop, pl->dev.logN2, 1.0 / (double)g.hop};
+                fill_scan_cfg(&cfg, set ? c->stats32_b.p : c->stats32.p, set ? c->wflags_b.p : c->wflags.p, out_count, scan.margin,
+                              scan.seg_c, scan.seg_d);
+                scan.sparse = sparse_view(cfg, g.hop, pl->dev.logN2);
             }
             const float factor = scale_factor(h, p->scale, 1);
             const HalfScale hs = half_scale(h, o, pl->dev);
@@ -1196,18 +1200,15 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
         for (size_t j = 0; j < nn; ++j) {
-            am_needle* h = needles[j];
             const SegHeader* hd = h_hdr + hdr_of(k, j);
             const size_t slot = G(k) * nn + j;
             // Non-finite samples poison whole block pairs for every needle (see match_many): such a
             // haystack goes through the single-needle path, which gives every window the reference's
-            // answer, and teaches the write threshold nothing.  So does a pair with a failed
-            // certificate, a lost spill or more than AM_MAX_PEAKS_PER_CHUNK peaks in a chunk.
+            // answer.  So does a pair with a failed certificate, a lost spill or more than
+            // AM_MAX_PEAKS_PER_CHUNK peaks in a chunk.
             bool again = h_bad[k] != 0;
-            for (int i = 0; i < ns && !h_bad[k]; ++i) {
+            for (int i = 0; i < ns && !again; ++i)
                 if (hd[i].overflow & 7) again = true;
-                if (!h->have_min[sm] || hd[i].seg_min < h->min_seg_min[sm]) { h->min_seg_min[sm] = hd[i].seg_min; h->have_min[sm] = true; }
-            }
             if (again) { redo.emplace_back(k, j); continue; }
             all.clear();
             for (int i = 0; i < ns; ++i) append_header_peaks(hd[i], arena, all);
@@ -1657,6 +1658,30 @@ int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float
     if (n == 0) return AM_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     AM_HIP(launch_axpy(c->stream, d_dst, d_src, (long long)n, gain));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_synth_pcm16_stereo_device(int device, int16_t* d_out, uint32_t seed, uint32_t stream, uint64_t first, size_t frames, float amp) {
+    if (!d_out) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (frames == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    AM_HIP(launch_synth_pcm16(c->stream, d_out, seed, stream, first, (long long)frames, amp));
+    AM_HIP(hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_add_pcm16_device(int device, int16_t* d_dst, const int16_t* d_src, size_t frames) {
+    if (!d_dst || !d_src) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    if (frames == 0) return AM_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    AM_HIP(launch_add_pcm16(c->stream, d_dst, d_src, (long long)frames));
     AM_HIP(hipStreamSynchronize(c->stream));
     return AM_OK;
 }

@@ -975,6 +975,12 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
 // Score-scan exchange of K3: the workgroup's 256 x 32 scores of one block go through LDS
 // once so that every thread ends up with the whole 32-score run of one row; (min, max) of a
 // run then cost 16 + 16 three-input operations.
@@ -1111,7 +1117,8 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
         sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
     }
-    bool wantA = true, wantB = true;
+    // which of this thread's 16 rows leave the chip as raw scores (bit a = row a * 2^HB + hi), per block
+    unsigned wantA = 0xFFFFu, wantB = 0xFFFFu;
     if (scan.stats32 != nullptr) {
         // ---- fused score scan: (min,max) per 32 consecutive scores ------------
         // this thread owns the run of row n1 = row (scores row*out_stride + n2_0 .. +31 of both blocks)
@@ -1131,8 +1138,29 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         scan_put<HB>(lds2, hi, cp, sb0, sb1);
         wave_sync_lds();
         scan_row_minmax<HB>(lds4, row, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
-        // raw scores leave the chip only for tiles that can matter to the peak
-        // pick: some score >= theta, or a run that straddles a chunk edge
+        // Raw scores leave the chip only for RUNS that can matter to the peak pick: a run whose maximum
+        // reaches the tile's write threshold, or one that straddles a chunk edge.  The threshold is the
+        // tile's own: its 2^(HB+4) runs are spread evenly over the whole block (one every out_stride
+        // scores), so their minimum is a good estimate of the minimum of the chunks in that block, and
+        // the threshold sits `margin` (half a prominence) above it.  The pick checks, per chunk, that no
+        // tile's threshold was too high (the certificate in peaks_kernel): estimate and decision need
+        // no history and no second pass.
+        float tminA = wave_min_f(leftA > 0 ? rmnA : FLT_MAX), tminB = wave_min_f(leftB > 0 ? rmnB : FLT_MAX);
+        // every wavefront leaves its two minima in the first words of a scan row of its own (its lanes are
+        // done reading it: the reads above were waited for before the minima could be formed), so the
+        // kernel needs no LDS beyond the tile
+        float* slots = reinterpret_cast<float*>(lds2 + scan_row_of<HB>(t & ~63) * 16);   // row of the wave's lane 0
+        wave_sync_lds();
+        if ((t & 63) == 0) { slots[0] = tminA; slots[1] = tminB; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < (1 << (HB - 2)); ++w) {
+            const float* v = reinterpret_cast<const float*>(lds2 + scan_row_of<HB>(w * 64) * 16);
+            tminA = fminf(tminA, v[0]);
+            tminB = fminf(tminB, v[1]);
+        }
+        const bool dense = scan.margin < 0.0f;
+        const float thA = dense ? -FLT_MAX : tminA + scan.margin, thB = dense ? -FLT_MAX : tminB + scan.margin;
         bool edgeA, edgeB;
         if (one_edge) {
             const unsigned long long loA = (unsigned long long)(outA + rowrun), loB = (unsigned long long)(outB + rowrun);
@@ -1142,33 +1170,34 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
             edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
             edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
         }
-        // one block-wide vote for both blocks: every wavefront leaves its two ballots in the first
-        // words of a scan row of its own (its lanes are done reading it: the reads above were
-        // waited for before rmx could be compared), so the kernel needs no LDS beyond the 32 KB tile
-        const bool pa = (leftA > 0 && rmxA >= scan.theta) || edgeA, pb = (leftB > 0 && rmxB >= scan.theta) || edgeB;
+        const bool pa = (leftA > 0 && rmxA >= thA) || edgeA, pb = (leftB > 0 && rmxB >= thB) || edgeB;
+        // The owner of row a * 2^HB + hi is lane (a << 2) | (hi & 3) of the wavefront that holds the column
+        // owners (hi, *) (scan_row_of): the row's 16 writers read its decision out of a ballot.
         const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
-        int* votes = reinterpret_cast<int*>(lds2 + scan_row_of<HB>(t & ~63) * 16);   // row of the wave's lane 0
-        wave_sync_lds();
-        if ((t & 63) == 0) { votes[0] = ba != 0ull; votes[1] = bb != 0ull; }
-        __syncthreads();
-        wantA = false; wantB = false;
+        wantA = 0u; wantB = 0u;
 #pragma unroll
-        for (int w = 0; w < (1 << (HB - 2)); ++w) {
-            const int* v = reinterpret_cast<const int*>(lds2 + scan_row_of<HB>(w * 64) * 16);
-            wantA = wantA || v[0] != 0;
-            wantB = wantB || v[1] != 0;
+        for (int a = 0; a < 16; ++a) {
+            wantA |= (unsigned)((ba >> ((a << 2) | (hi & 3))) & 1ull) << a;
+            wantB |= (unsigned)((bb >> ((a << 2) | (hi & 3))) & 1ull) << a;
         }
-        if (t == 0 && scan.wflags != nullptr) {
+        if (t == 0 && scan.tile_theta != nullptr) {
             const unsigned tile = (unsigned)n2_0 >> kColsLog;
-            scan.wflags[blkA * (out_stride >> kColsLog) + tile] = wantA ? 1 : 0;
-            if (blkB < job.nblocks) scan.wflags[blkB * (out_stride >> kColsLog) + tile] = wantB ? 1 : 0;
+            scan.tile_theta[blkA * (out_stride >> kColsLog) + tile] = thA;
+            if (blkB < job.nblocks) scan.tile_theta[blkB * (out_stride >> kColsLog) + tile] = thB;
         }
-        if (leftA > 0) scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
-        if (leftB > 0) scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
+        if (leftA > 0) {
+            scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
+            if (scan.wflags != nullptr) scan.wflags[(outA + rowrun) >> 5] = pa ? 1 : 0;
+        }
+        if (leftB > 0) {
+            scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
+            if (scan.wflags != nullptr) scan.wflags[(outB + rowrun) >> 5] = pb ? 1 : 0;
+        }
     }
     if (wantA) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
+            if (!((wantA >> a) & 1u)) continue;
             const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
             // hop and out offsets are even whenever this kernel is used, so a pair is
             // valid or invalid as a whole except at the very end of the score array
@@ -1182,6 +1211,7 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
     if (wantB) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
+            if (!((wantB >> a) & 1u)) continue;
             const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
             if (dst8 && n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(sb0[a], sb1[a]);
             else {

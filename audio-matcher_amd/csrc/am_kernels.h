@@ -68,9 +68,11 @@ hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const
 // (plain correlation: every score is written).
 struct ScanCfg {
     float2* stats32;          // (min,max) per 32 consecutive scores, always written
-    unsigned char* wflags;    // [block][column tile] = 1 when the tile's raw scores were written
-    float theta;              // raw scores are written for tiles with a score >= theta ...
-    long long seg_c, seg_d;   // ... and for runs that hold score i*seg_c or i*seg_c + seg_d (chunk edges)
+    unsigned char* wflags;    // one byte per 32-score run of the score array: 1 = its raw scores were written
+    float* tile_theta;        // [block][column tile]: the write threshold that tile used in that block
+    float margin;             // a run's raw scores are written when its maximum >= (the tile's minimum in the block) + margin
+                              // (and for runs that hold a chunk edge); margin < 0: every run is written
+    long long seg_c, seg_d;   // chunk geometry: runs that hold score i*seg_c or i*seg_c + seg_d are chunk edges
     double inv_c;             // 1.0 / seg_c
 };
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
@@ -108,13 +110,12 @@ struct PeakArena {
     unsigned* cursor;
     unsigned cap;
 };
-// Which raw scores exist (K3 writes them sparsely): wflags == nullptr means all.
+// Which raw scores exist (K3 writes them sparsely, run by run): wflags == nullptr means all.
 struct SparseScores {
-    const unsigned char* wflags;
+    const unsigned char* wflags;   // one byte per 32-score run
     const float2* stats32;
-    float theta;
+    const float* tile_theta;       // [block][column tile] thresholds K3 used (the pick's certificate reads them)
     int hop, log_n2;
-    double inv_hop;
 };
 // Hand-over of chunks with many candidate tiles from peaks_kernel to peaks_wide /
 // peaks_finish (device memory, one entry per chunk of the launch; list: AM_MAX_PEAKS_PER_CHUNK
@@ -151,6 +152,8 @@ hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_p
 hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
                         long long n, float amp);
 hipError_t launch_axpy(hipStream_t st, float* dst, const float* src, long long n, float gain);
+hipError_t launch_synth_pcm16(hipStream_t st, int16_t* out, uint32_t seed, uint32_t stream, uint64_t first, long long frames, float amp);
+hipError_t launch_add_pcm16(hipStream_t st, int16_t* dst, const int16_t* src, long long frames);
 hipError_t launch_pcm_downmix(hipStream_t st, const int16_t* in, long long frames, float* out);
 
 }  // namespace am

@@ -102,25 +102,18 @@ __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s
 // ---------------------------------------------------------------------------
 struct Cand { long long ps, pe; float h; };
 
-// K3 writes raw scores only for tiles that can matter (am_fft.hip); everywhere
-// else only the per-32 summary exists.
+// K3 writes raw scores only for the 32-score runs that can matter (am_fft.hip, k3_finish);
+// everywhere else only the per-32 summary exists.
 __device__ __forceinline__ bool run_written(const SparseScores& sp, long long idx) {
-    if (sp.wflags == nullptr) return true;
-    // idx / hop through one f64 multiply and a fix-up (idx < 2^50)
-    long long blk = (long long)((double)idx * sp.inv_hop);
-    long long rem = idx - blk * sp.hop;
-    if (rem < 0) { rem += sp.hop; --blk; }
-    else if (rem >= sp.hop) { rem -= sp.hop; ++blk; }
-    const unsigned n = (unsigned)rem;
-    const unsigned tile = (n & ((1u << sp.log_n2) - 1u)) >> 5;
-    return sp.wflags[blk * (long long)(1 << (sp.log_n2 - 5)) + tile] != 0;
+    return sp.wflags == nullptr || sp.wflags[idx >> 5] != 0;
 }
 // for minima: exact where written, else the run's minimum (exact whenever the
 // whole run lies in the range being reduced, a lower bound otherwise)
 __device__ __forceinline__ float score_for_min(const float* __restrict__ g, const SparseScores& sp, long long idx) {
     return run_written(sp, idx) ? g[idx] : sp.stats32[idx >> 5].x;
 }
-// for comparisons with a candidate height (>= theta): an unwritten score is < theta
+// for comparisons with a candidate height: an unwritten score lies below the write threshold of its
+// tile, which the chunk's certificate (peaks_kernel) has shown to be below every candidate height
 __device__ __forceinline__ float score_for_cmp(const float* __restrict__ g, const SparseScores& sp, long long idx) {
     return run_written(sp, idx) ? g[idx] : -FLT_MAX;
 }
@@ -703,12 +696,26 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     if (tid == 0) seg_min_s = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
     __syncthreads();
     const float seg_min = seg_min_s;
-    // Sparse raw scores are sufficient only if every score that can qualify
-    // (x - seg_min >= min_prom) was written (x >= theta); otherwise report it and
-    // let the host redo this chunk with theta = -inf.
-    if (sp.wflags != nullptr && !((sp.theta - seg_min) < min_prom)) {
-        if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
-        return;
+    // Sparse raw scores are sufficient only if every score that can qualify (x - seg_min >= min_prom)
+    // was written.  A run is written when its maximum reaches the threshold of its K3 tile (tile
+    // minimum in the block + half a prominence, am_fft.hip): every threshold used for a block that
+    // overlaps this chunk must therefore lie less than min_prom above the chunk's minimum (then
+    // every candidate and everything that can stop a prominence walk was written).  Otherwise
+    // report it and let the host redo this chunk with everything written.
+    if (sp.wflags != nullptr) {
+        __shared__ float th_s[kWaves];
+        const int tiles = 1 << (sp.log_n2 - kColsLog);
+        const long long b0 = a / sp.hop, b1 = (b - 1) / sp.hop;
+        float th = -FLT_MAX;
+        for (long long i = b0 * tiles + tid; i < (b1 + 1) * tiles; i += kPeakThreads) th = fmaxf(th, sp.tile_theta[i]);
+        th = wave_max(th);
+        if (lane == 0) th_s[wv] = th;
+        __syncthreads();
+        th = fmaxf(fmaxf(th_s[0], th_s[1]), fmaxf(th_s[2], th_s[3]));
+        if (!((th - seg_min) < min_prom)) {
+            if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
+            return;
+        }
     }
 
     // ---- the chunk's maximum first -------------------------------------------
@@ -1154,6 +1161,34 @@ __global__ void __launch_bounds__(256) synth_kernel(float* __restrict__ out, uin
     }
 }
 
+// the same signal as interleaved i16 stereo frames: channel L = stream,
+// channel R = stream + 5000, each rint(uniform * amp * 32767) (round half to even), saturated
+__device__ __forceinline__ float synth_value(uint32_t seed, uint32_t stream, uint64_t i, float amp) {
+    const uint32_t key = fmix32(seed * 0x9E3779B9u + stream * 0x7F4A7C15u + 0x01234567u);
+    uint32_t h = fmix32((uint32_t)i ^ key);
+    h = fmix32(h + stream * 0x9E3779B9u + (uint32_t)(i >> 32) * 0xC2B2AE35u + seed);
+    const int32_t v = (int32_t)(h >> 8) - (1 << 23);
+    return __fmul_rn(__fmul_rn((float)v, 1.0f / 8388608.0f), amp);
+}
+__device__ __forceinline__ short to_s16(float x) {
+    const float r = rintf(__fmul_rn(x, 32767.0f));
+    return (short)fminf(fmaxf(r, -32768.0f), 32767.0f);
+}
+__global__ void __launch_bounds__(256) synth_pcm16_kernel(short2* __restrict__ out, uint32_t seed, uint32_t stream,
+                                                          uint64_t first, long long frames, float amp) {
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < frames; k += (long long)gridDim.x * 256) {
+        const uint64_t i = first + (uint64_t)k;
+        out[k] = make_short2(to_s16(synth_value(seed, stream, i, amp)), to_s16(synth_value(seed, stream + 5000u, i, amp)));
+    }
+}
+// dst[i] = saturate(dst[i] + src[i]) on interleaved i16 values (plants a needle into a haystack)
+__global__ void __launch_bounds__(256) add_pcm16_kernel(short* __restrict__ dst, const short* __restrict__ src, long long n) {
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) {
+        const int v = (int)dst[k] + (int)src[k];
+        dst[k] = (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+    }
+}
+
 __global__ void __launch_bounds__(256) axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n, float gain) {
     for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256)
         dst[k] = __fadd_rn(dst[k], __fmul_rn(gain, src[k]));
@@ -1247,6 +1282,16 @@ hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_p
 hipError_t launch_synth(hipStream_t st, float* out, uint32_t seed, uint32_t stream, uint64_t first,
                         long long n, float amp) {
     hipLaunchKernelGGL(synth_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, seed, stream, first, n, amp);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_pcm16(hipStream_t st, int16_t* out, uint32_t seed, uint32_t stream, uint64_t first, long long frames, float amp) {
+    hipLaunchKernelGGL(synth_pcm16_kernel, dim3(grid_for(frames)), dim3(256), 0, st, reinterpret_cast<short2*>(out), seed, stream, first, frames, amp);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_pcm16(hipStream_t st, int16_t* dst, const int16_t* src, long long frames) {
+    hipLaunchKernelGGL(add_pcm16_kernel, dim3(grid_for(2 * frames)), dim3(256), 0, st, dst, src, 2 * frames);
     return hipGetLastError();
 }
 

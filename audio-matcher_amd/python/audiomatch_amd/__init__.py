@@ -111,6 +111,9 @@ _SIGNATURES = {
     "am_synth_uniform_device": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                           C.c_size_t, C.c_float]),
     "am_axpy_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
+    "am_synth_pcm16_stereo_device": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64,
+                                               C.c_size_t, C.c_float]),
+    "am_add_pcm16_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "am_set_progress_callback": (C.c_int, [C.c_void_p, C.c_void_p]),
     "am_set_chunk_progress_callback": (C.c_int, [C.c_void_p, C.c_void_p]),
     "am_needle_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
@@ -240,6 +243,18 @@ def synth_uniform_device(device: int, n: int, seed: int, stream: int, first: int
     buf = DeviceBuffer(device, n * 4)
     _check(lib().am_synth_uniform_device(device, buf.ptr, seed, stream, first, n, amp))
     return buf
+
+
+def synth_pcm16_stereo_device(device: int, frames: int, seed: int, stream: int, first: int = 0,
+                              amp: float = 0.25) -> DeviceBuffer:
+    """Interleaved i16 stereo frames of the synthetic signal (left = stream, right = stream + 5000)."""
+    buf = DeviceBuffer(device, frames * 4)
+    _check(lib().am_synth_pcm16_stereo_device(device, buf.ptr, seed, stream, first, frames, amp))
+    return buf
+
+
+def add_pcm16_device(device: int, dst: DeviceBuffer, dst_frame: int, src_ptr: int, frames: int):
+    _check(lib().am_add_pcm16_device(device, dst.ptr + 4 * dst_frame, src_ptr, frames))
 
 
 def axpy_device(device: int, dst: DeviceBuffer, dst_offset: int, src_ptr: int, n: int, gain: float = 1.0):

@@ -211,6 +211,13 @@ int am_synth_uniform_device(int device, float* d_out, uint32_t seed, uint32_t st
 /* d_dst[i] += gain * d_src[i]  (plants a needle into a haystack) */
 int am_axpy_device(int device, float* d_dst, const float* d_src, size_t n, float gain);
 
+/* the same signal as interleaved i16 stereo frames: left = stream,
+ * right = stream + 5000, each value rint(uniform * amp * 32767), saturated */
+int am_synth_pcm16_stereo_device(int device, int16_t* d_out, uint32_t seed, uint32_t stream,
+                                 uint64_t first, size_t frames, float amp);
+/* d_dst[i] = saturate(d_dst[i] + d_src[i]) over 2 * frames interleaved i16 values (plants a needle) */
+int am_add_pcm16_device(int device, int16_t* d_dst, const int16_t* d_src, size_t frames);
+
 /* ---- the haystack batch over every GPU of a node ----------------------------- */
 /* matcher::run's per-file loop (matcher/mod.rs:42-87) sharded over devices: haystacks are
  * independent given the needle (audio_matcher.rs:114-131), so haystack k goes to pool slot

@@ -176,6 +176,29 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
 
 
+@pytest.mark.parametrize("config", [3, 4])
+def test_bench_config_legs_shard_the_same_way(config):
+    """`bench.py --config 3 / 4 --gpus 3 --dry-shard`: BASELINE configs[3] (32 needles) and
+    configs[4] (48 kHz i16 stereo, f16) shard their haystacks k mod N like the headline."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(config), "--gpus", "3", "--dry-shard",
+                        "--total-haystacks", "1000"], capture_output=True, text=True, timeout=300)
+    plans = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")), key=lambda p: p["rank"])
+    assert [p["config"] for p in plans] == [config] * 3
+    assert [p["count"] for p in plans] == [334, 333, 333] and [p["first"][0] for p in plans] == [0, 1, 2]
+    assert [p["last"] for p in plans] == [999, 997, 998]
+
+
+def test_bench_workloads_state_their_design_bytes():
+    """The per-kernel algorithmic bytes bench.py prices each config's roofline on."""
+    sys.path.insert(0, ROOT)
+    import bench
+    g = bench.plan_geometry(441000, 158760000)
+    assert g == {"log_n": 22, "n_fft": 1 << 22, "hop": 3752960, "out_count": 158319001, "nblocks": 43, "npairs": 22}
+    g4 = bench.plan_geometry(480000, 172800000)
+    assert g4["npairs"] == 24 and g4["hop"] == 3714048 and g4["nblocks"] == 47
+
+
 def test_isa_has_no_store_data_hazard(tmp_path):
     """The gfx950 store-data hazard of DESIGN.md section 3: no >64-bit store in the compiled
     kernels may have one of its data VGPRs overwritten after fewer than two wait states

@@ -44,7 +44,7 @@ def multi_inputs(oracle, sr, n_needles=3):
     s = 3 * sr
     needles = [oracle.synth_uniform(31, 200 + j, 0, s) for j in range(n_needles)]
     lens = [170 * sr, 25 * sr, s - 5, 0, 95 * sr + 321]
-    plants = {0: {0: [12.0, 100.5], 1: [60.0], 2: []},
+    plants = {0: {0: [12.0, 100.5], 1: [61.0], 2: []},
               1: {0: [], 1: [20.25], 2: [5.0]},
               4: {0: [33.0], 1: [], 2: [70.0, 88.0]}}
     hays = []
