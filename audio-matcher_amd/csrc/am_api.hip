@@ -277,6 +277,23 @@ struct am_needle {
     float inv_autocorr = 0.f;
     std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
     std::map<int, unsigned*> spectra16;   // logN -> the same as scaled __half2 points (half_pipeline = 2)
+    // Lowest chunk minimum of each of the last few haystacks matched with this needle (index 0:
+    // unscaled scores, 1: AM_SCALE_LIB).  Bounds the raw-score write threshold from above, so that a
+    // score array that drifts slowly (chunk minimum in another block pair than a tile's scores)
+    // stays inside its certificate; a ring, so that one unusual haystack is forgotten again.
+    static constexpr int kRecent = 8;
+    float recent_min[2][kRecent];
+    int recent_n[2] = {0, 0}, recent_pos[2] = {0, 0};
+    void remember_min(int sm, float v) {
+        recent_min[sm][recent_pos[sm]] = v;
+        recent_pos[sm] = (recent_pos[sm] + 1) % kRecent;
+        if (recent_n[sm] < kRecent) ++recent_n[sm];
+    }
+    float hist_min(int sm) const {
+        float m = FLT_MAX;
+        for (int i = 0; i < recent_n[sm]; ++i) m = std::min(m, recent_min[sm][i]);
+        return m;
+    }
     // per-handle overrides of the process-wide option defaults (-1 = follow the default)
     long long opt_log_n = -1, opt_half = -1;
 };
@@ -379,7 +396,8 @@ static int needle_spectrum16(am_needle* h, const Plan* pl, float hscale, const f
 // When a ScanRequest is given and the plan supports it, K3 also writes the level-0
 // (min,max) summary into the chosen set's stats32 and `fused` becomes true.
 struct ScanRequest {
-    float margin;            // in: a run's raw scores are written when its maximum reaches its K3 tile's minimum + margin; < 0: all
+    float margin;            // in: a run's raw scores are written when its maximum reaches min(its K3 tile's minimum, hist_min) + margin; < 0: all
+    float hist_min;          // in: lowest chunk minimum of the needle's recent haystacks (FLT_MAX: none)
     long long seg_c, seg_d;  // in: chunk geometry (scores i*seg_c .. i*seg_c + seg_d)
     int set;                 // in: which set of score-side buffers (0, or 1 in an overlapped batch)
     hipEvent_t before_k3;    // in: K3 must not overwrite that set before this event (or null)
@@ -427,24 +445,29 @@ static HalfScale half_scale(const am_needle* h, const Opts& o, const PlanDev& pl
     return s;
 }
 
-// Layout of a set's sparse-score side buffer: one byte per 32-score run (was it written?), then the
-// write thresholds K3 used, one float per (block, column tile).
-static size_t sparse_flag_bytes(long long out_count) { return ((size_t)((out_count + 31) / 32) + 255) / 256 * 256; }
-static size_t sparse_bytes(long long out_count, long long nblocks, int logN2) {
-    return sparse_flag_bytes(out_count) + sizeof(float) * ((size_t)nblocks << (logN2 - kColsLog));
+// Layout of a set's sparse-score side buffer: the ballots of K3's wavefronts (one 64-bit word per
+// block, column tile and wavefront: which of the tile's runs were written), then the write
+// thresholds K3 used, one float per (block, column tile).
+static size_t sparse_word_bytes(long long nblocks, const PlanDev& pl) {
+    return sizeof(unsigned long long) * (((size_t)nblocks << (pl.logN2 - kColsLog)) << (pl.logN1 - 6));
 }
-static void fill_scan_cfg(ScanCfg* cfg, void* stats32, void* side, long long out_count, float margin, long long seg_c, long long seg_d) {
+static size_t sparse_bytes(long long nblocks, const PlanDev& pl) {
+    return sparse_word_bytes(nblocks, pl) + sizeof(float) * ((size_t)nblocks << (pl.logN2 - kColsLog));
+}
+static void fill_scan_cfg(ScanCfg* cfg, void* stats32, void* side, long long nblocks, const PlanDev& pl, float margin, float hist_min,
+                          long long seg_c, long long seg_d) {
     cfg->stats32 = static_cast<float2*>(stats32);
-    cfg->wflags = static_cast<unsigned char*>(side);
-    cfg->tile_theta = reinterpret_cast<float*>(static_cast<char*>(side) + sparse_flag_bytes(out_count));
+    cfg->wbits = static_cast<unsigned long long*>(side);
+    cfg->tile_theta = reinterpret_cast<float*>(static_cast<char*>(side) + sparse_word_bytes(nblocks, pl));
     cfg->margin = margin;
+    cfg->hist_min = hist_min;
     cfg->seg_c = seg_c; cfg->seg_d = seg_d;
     cfg->inv_c = seg_c > 0 ? 1.0 / (double)seg_c : 0.0;
 }
 // what the peak pick sees of it: with every run written (margin < 0) it needs neither flags nor thresholds
-static SparseScores sparse_view(const ScanCfg& cfg, long long hop, int logN2) {
-    if (cfg.margin < 0.0f) return SparseScores{nullptr, cfg.stats32, nullptr, (int)hop, logN2};
-    return SparseScores{cfg.wflags, cfg.stats32, cfg.tile_theta, (int)hop, logN2};
+static SparseScores sparse_view(const ScanCfg& cfg, long long hop, const PlanDev& pl) {
+    if (cfg.margin < 0.0f) return SparseScores{nullptr, cfg.stats32, nullptr, (int)hop, pl.logN2, pl.logN1, 1.0 / (double)hop};
+    return SparseScores{cfg.wbits, cfg.stats32, cfg.tile_theta, (int)hop, pl.logN2, pl.logN1, 1.0 / (double)hop};
 }
 
 static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
@@ -455,7 +478,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         // tiny needle: direct summation, every score written, no fused scan
         if (scan_req) {
             scan_req->fused = false;
-            scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, 1, 5};
+            scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, 1, 5, 5, 1.0};
         }
         Job job{};
         job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
@@ -478,15 +501,15 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     ScanCfg scan{};
     if (scan_req) {
         scan_req->fused = false;
-        scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, (int)hop, pl->dev.logN2};
+        scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, (int)hop, pl->dev.logN2, pl->dev.logN1, 1.0 / (double)hop};
         if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
             DevBuf& b32 = scan_req->set ? c->stats32_b : c->stats32;
             DevBuf& bwf = scan_req->set ? c->wflags_b : c->wflags;
             if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-            if ((rc = bwf.ensure(sparse_bytes(out_count, nblocks, pl->dev.logN2)))) return rc;
-            fill_scan_cfg(&scan, b32.p, bwf.p, out_count, scan_req->margin, scan_req->seg_c, scan_req->seg_d);
+            if ((rc = bwf.ensure(sparse_bytes(nblocks, pl->dev)))) return rc;
+            fill_scan_cfg(&scan, b32.p, bwf.p, nblocks, pl->dev, scan_req->margin, scan_req->hist_min, scan_req->seg_c, scan_req->seg_d);
             scan_req->fused = true;
-            scan_req->sparse = sparse_view(scan, hop, pl->dev.logN2);
+            scan_req->sparse = sparse_view(scan, hop, pl->dev);
         }
     }
     // half-precision storage of the work matrix: K2 normalises by the needle
@@ -602,7 +625,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     DevBuf& bstats = set ? c->stats_b : c->stats;
     DevBuf& bpeaks = set ? c->peaks_b : c->peaks;
     const float2* d_stats32 = (scan && scan->fused) ? scan->sparse.stats32 : nullptr;
-    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5};
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5, 5, 1.0};
     if (nsegs == 0 || n_scores <= 0) return AM_OK;
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;
@@ -646,7 +669,7 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
                           std::vector<am_peak>& all) {
     const long long a = sg.a, b = std::min(sg.b, n_scores);
     if (b - a >= 0xFFFFFFFFll) return fail(AM_ERR_PEAK_OVERFLOW, "chunk of 2^32 scores or more with more than AM_MAX_PEAKS_PER_CHUNK peaks");
-    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5};
+    const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5, 5, 1.0};
     int rc;
     if ((rc = c->wide_ctl.ensure(24))) return rc;
     struct Ctl { unsigned long long best; int state; unsigned count; float seg_min; int ntiles; } ctl{0ull, 7, 0u, seg_min, -1};   // (state: handed over, head and tail pieces to be scanned)
@@ -818,9 +841,11 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // The peak kernel certifies per chunk that every threshold was low enough; a chunk that fails
     // (a dip deeper than half a prominence that most tiles' samples missed) is redone with every
     // run written.
+    const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
     const bool sparse_ok = !my && !o.dense && p->min_prominence > 0.f;
     ScanRequest scan{};
     scan.margin = sparse_ok ? 0.5f * p->min_prominence : -1.0f;
+    scan.hist_min = h->hist_min(sm);   // (of the haystacks before this call: the whole batch is queued before any result is back)
     scan.seg_c = (long long)p->chunk;
     scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
     // main-pass segments of every haystack, back to back; MyConvolve scaling keeps the
@@ -932,6 +957,11 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         const int s0 = seg_off[k], s1 = seg_off[k + 1];
         if (n_chunks[k] == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
+        if (!my && !h_bad[k] && s1 > s0) {   // (a haystack with non-finite scores teaches the threshold nothing)
+            float lowest = FLT_MAX;
+            for (int i = s0; i < s1; ++i) lowest = std::min(lowest, h_hdr[i].seg_min);
+            h->remember_min(sm, lowest);
+        }
         all.clear();
         // Non-finite samples (NaN, +-inf; f32 sources only).  The reference transforms every window
         // on its own (audio_matcher.rs:114-122): a window that holds such a sample gets NaN scores
@@ -1060,6 +1090,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         return fail(AM_ERR_INVALID_ARG, "am_match_multi supports AM_SCALE_NONE and AM_SCALE_LIB");
     for (size_t k = 0; k < n_hay; ++k)
         for (size_t j = 0; j < nn; ++j) n_out[G(k) * nn + j] = 0;
+    const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
     // the chunk lists of every haystack, back to back, and each haystack's block layout
     std::vector<Segment> segs;
     std::vector<int> seg_off(n_hay + 1, 0);
@@ -1079,7 +1110,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         max_segs = std::max(max_segs, ns);
         max_work = std::max(max_work, matrix);
         max_matrix = std::max(max_matrix, matrix);
-        max_wflags = std::max(max_wflags, sparse_bytes(out_count, geo[k].nblocks, 13));   // (at most 2^13 / 32 column tiles per block)
+        { const Plan* plk = nullptr; if ((rc = get_plan(c, geo[k].logN, &plk))) return rc; max_wflags = std::max(max_wflags, sparse_bytes(geo[k].nblocks, plk->dev)); }
     }
     seg_off[n_hay] = (int)segs.size();
     const size_t nsegs = segs.size();
@@ -1161,16 +1192,17 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             ScanRequest scan{};
             scan.set = set;
             scan.margin = (!o.dense && p->min_prominence > 0.f) ? 0.5f * p->min_prominence : -1.0f;
+            scan.hist_min = h->hist_min(sm);
             scan.seg_c = (long long)p->chunk;
             scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
             scan.bad = src_kind == 0 ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
             scan.fused = fused;
-            scan.sparse = SparseScores{nullptr, nullptr, nullptr, (int)g.hop, pl->dev.logN2};
+            scan.sparse = SparseScores{nullptr, nullptr, nullptr, (int)g.hop, pl->dev.logN2, pl->dev.logN1, 1.0 / (double)g.hop};
             ScanCfg cfg{};
             if (fused) {
-                fill_scan_cfg(&cfg, set ? c->stats32_b.p : c->stats32.p, set ? c->wflags_b.p : c->wflags.p, out_count, scan.margin,
-                              scan.seg_c, scan.seg_d);
-                scan.sparse = sparse_view(cfg, g.hop, pl->dev.logN2);
+                fill_scan_cfg(&cfg, set ? c->stats32_b.p : c->stats32.p, set ? c->wflags_b.p : c->wflags.p, g.nblocks, pl->dev, scan.margin,
+                              scan.hist_min, scan.seg_c, scan.seg_d);
+                scan.sparse = sparse_view(cfg, g.hop, pl->dev);
             }
             const float factor = scale_factor(h, p->scale, 1);
             const HalfScale hs = half_scale(h, o, pl->dev);
@@ -1207,8 +1239,12 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             // answer.  So does a pair with a failed certificate, a lost spill or more than
             // AM_MAX_PEAKS_PER_CHUNK peaks in a chunk.
             bool again = h_bad[k] != 0;
-            for (int i = 0; i < ns && !again; ++i)
+            float lowest = FLT_MAX;
+            for (int i = 0; i < ns && !again; ++i) {
                 if (hd[i].overflow & 7) again = true;
+                lowest = std::min(lowest, hd[i].seg_min);
+            }
+            if (!again) needles[j]->remember_min(sm, lowest);
             if (again) { redo.emplace_back(k, j); continue; }
             all.clear();
             for (int i = 0; i < ns; ++i) append_header_peaks(hd[i], arena, all);

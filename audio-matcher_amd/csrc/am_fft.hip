@@ -919,7 +919,11 @@ hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n
 // own work matrix.  Per needle the row costs 8/n + 8 bytes of HBM traffic instead of
 // 16 and the forward half of the arithmetic is shared.
 #ifndef AM_K2G_PREFETCH
-#define AM_K2G_PREFETCH 1    // request the first quarter of the next needle's spectrum row one needle ahead
+// 1 = request the first quarter of the next needle's spectrum row one needle ahead.  Measured and dropped
+// (profiles/r03/k2_group_ab.txt): the 16 registers it holds across the inverse passes push the kernel
+// from 230 to 256 VGPRs plus 15 spilled ones (64 bytes of scratch per lane, reloaded inside the needle
+// loop): 2.16 ms per launch of 8 needles x 22 pairs with it, 1.60 ms without.
+#define AM_K2G_PREFETCH 0
 #endif
 #ifndef AM_K2G_STORE_AUX
 #define AM_K2G_STORE_AUX 0   // cache policy of the eight write streams (2 = nt)
@@ -936,8 +940,6 @@ k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsi
     k2_forward12<false>(k, rrow, lds4);
     float2 z[32];
     k2_forward3(k, lds4, z);
-    // the first quarter of a needle's spectrum row is requested one needle ahead, so
-    // that its latency hides behind the previous needle's inverse passes
     float4 hq[4];
     if (AM_K2G_PREFETCH) k2_fetch_quarter(make_rsrc(reinterpret_cast<const float4*>(grp.hc[0]) + hoff4, kN2 * 8), k.voff, 0, hq);
 #pragma unroll 1
@@ -975,10 +977,21 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
+// Minimum over the wavefront's 64 lanes through DPP (no LDS round trips): four row_shr steps leave the
+// minimum of each 16-lane row in its last lane, row_bcast:15 / :31 carry it across the rows into
+// lane 63, which is read back as a scalar.  A lane without a source keeps its own value (`old`).
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    auto step = [](float x, auto ctrl, auto row_mask) {
+        const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        return fminf(x, __int_as_float(y));
+    };
+    v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+    v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+    v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+    v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Score-scan exchange of K3: the workgroup's 256 x 32 scores of one block go through LDS
@@ -1159,8 +1172,10 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
             tminA = fminf(tminA, v[0]);
             tminB = fminf(tminB, v[1]);
         }
+        // (hist_min: the lowest chunk minimum of the needle's last few haystacks, or FLT_MAX -- it keeps a
+        // chunk whose minimum lies in another block pair than this tile's scores inside its certificate)
         const bool dense = scan.margin < 0.0f;
-        const float thA = dense ? -FLT_MAX : tminA + scan.margin, thB = dense ? -FLT_MAX : tminB + scan.margin;
+        const float thA = dense ? -FLT_MAX : fminf(fminf(tminA, tminB), scan.hist_min) + scan.margin, thB = thA;
         bool edgeA, edgeB;
         if (one_edge) {
             const unsigned long long loA = (unsigned long long)(outA + rowrun), loB = (unsigned long long)(outB + rowrun);
@@ -1180,19 +1195,19 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
             wantA |= (unsigned)((ba >> ((a << 2) | (hi & 3))) & 1ull) << a;
             wantB |= (unsigned)((bb >> ((a << 2) | (hi & 3))) & 1ull) << a;
         }
+        // what was written, for the peak pick: the threshold per (block, tile) and the wavefront's ballot
+        // (bit (a << 2) | j = row a * 2^HB + 4 w + j of the tile) per (block, tile, wavefront)
+        const long long tileA = blkA * (out_stride >> kColsLog) + ((unsigned)n2_0 >> kColsLog), tileB = tileA + (out_stride >> kColsLog);
         if (t == 0 && scan.tile_theta != nullptr) {
-            const unsigned tile = (unsigned)n2_0 >> kColsLog;
-            scan.tile_theta[blkA * (out_stride >> kColsLog) + tile] = thA;
-            if (blkB < job.nblocks) scan.tile_theta[blkB * (out_stride >> kColsLog) + tile] = thB;
+            scan.tile_theta[tileA] = thA;
+            if (blkB < job.nblocks) scan.tile_theta[tileB] = thB;
         }
-        if (leftA > 0) {
-            scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
-            if (scan.wflags != nullptr) scan.wflags[(outA + rowrun) >> 5] = pa ? 1 : 0;
+        if ((t & 63) == 0 && scan.wbits != nullptr) {
+            scan.wbits[(tileA << (HB - 2)) + (t >> 6)] = ba;
+            if (blkB < job.nblocks) scan.wbits[(tileB << (HB - 2)) + (t >> 6)] = bb;
         }
-        if (leftB > 0) {
-            scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
-            if (scan.wflags != nullptr) scan.wflags[(outB + rowrun) >> 5] = pb ? 1 : 0;
-        }
+        if (leftA > 0) scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
+        if (leftB > 0) scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
     }
     if (wantA) {
 #pragma unroll

@@ -68,10 +68,13 @@ hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const
 // (plain correlation: every score is written).
 struct ScanCfg {
     float2* stats32;          // (min,max) per 32 consecutive scores, always written
-    unsigned char* wflags;    // one byte per 32-score run of the score array: 1 = its raw scores were written
-    float* tile_theta;        // [block][column tile]: the write threshold that tile used in that block
-    float margin;             // a run's raw scores are written when its maximum >= (the tile's minimum in the block) + margin
-                              // (and for runs that hold a chunk edge); margin < 0: every run is written
+    // which 32-score runs were written: one 64-bit word per (block, column tile, wavefront of the tile's
+    // workgroup), bit (a << 2) | j = row a * (rows / 16) + 4 * wavefront + j of the tile
+    unsigned long long* wbits;
+    float* tile_theta;        // [block][column tile]: the write threshold that tile used
+    float margin;             // a run's raw scores are written when its maximum >= min(the tile's minimum over its block
+                              // pair, hist_min) + margin (and for runs that hold a chunk edge); margin < 0: every run
+    float hist_min;           // lowest chunk minimum of the needle's recent haystacks (FLT_MAX: none)
     long long seg_c, seg_d;   // chunk geometry: runs that hold score i*seg_c or i*seg_c + seg_d are chunk edges
     double inv_c;             // 1.0 / seg_c
 };
@@ -110,12 +113,13 @@ struct PeakArena {
     unsigned* cursor;
     unsigned cap;
 };
-// Which raw scores exist (K3 writes them sparsely, run by run): wflags == nullptr means all.
+// Which raw scores exist (K3 writes them sparsely, run by run): wbits == nullptr means all.
 struct SparseScores {
-    const unsigned char* wflags;   // one byte per 32-score run
+    const unsigned long long* wbits;   // see ScanCfg
     const float2* stats32;
-    const float* tile_theta;       // [block][column tile] thresholds K3 used (the pick's certificate reads them)
-    int hop, log_n2;
+    const float* tile_theta;           // thresholds K3 used (the pick's certificate reads them)
+    int hop, log_n2, log_n1;           // block geometry: score n of a block = row (n >> log_n2), column (n & (2^log_n2 - 1))
+    double inv_hop;
 };
 // Hand-over of chunks with many candidate tiles from peaks_kernel to peaks_wide /
 // peaks_finish (device memory, one entry per chunk of the launch; list: AM_MAX_PEAKS_PER_CHUNK

@@ -103,9 +103,20 @@ __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s
 struct Cand { long long ps, pe; float h; };
 
 // K3 writes raw scores only for the 32-score runs that can matter (am_fft.hip, k3_finish);
-// everywhere else only the per-32 summary exists.
+// everywhere else only the per-32 summary exists.  The flags are the ballots of K3's wavefronts.
 __device__ __forceinline__ bool run_written(const SparseScores& sp, long long idx) {
-    return sp.wflags == nullptr || sp.wflags[idx >> 5] != 0;
+    if (sp.wbits == nullptr) return true;
+    // idx / hop through one f64 multiply and a fix-up (idx < 2^50)
+    long long blk = (long long)((double)idx * sp.inv_hop);
+    long long rem = idx - blk * sp.hop;
+    if (rem < 0) { rem += sp.hop; --blk; }
+    else if (rem >= sp.hop) { rem -= sp.hop; ++blk; }
+    const unsigned n = (unsigned)rem;
+    const unsigned row = n >> sp.log_n2, tile = (n & ((1u << sp.log_n2) - 1u)) >> kColsLog;
+    const int hb = sp.log_n1 - 4;                              // rows per register index a of a column owner
+    const unsigned wave = (row >> 2) & ((1u << (hb - 2)) - 1u), bit = ((row >> hb) << 2) | (row & 3u);
+    const long long word = (((blk << (sp.log_n2 - kColsLog)) + tile) << (hb - 2)) + wave;
+    return (sp.wbits[word] >> bit) & 1ull;
 }
 // for minima: exact where written, else the run's minimum (exact whenever the
 // whole run lies in the range being reduced, a lower bound otherwise)
@@ -702,7 +713,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     // overlaps this chunk must therefore lie less than min_prom above the chunk's minimum (then
     // every candidate and everything that can stop a prominence walk was written).  Otherwise
     // report it and let the host redo this chunk with everything written.
-    if (sp.wflags != nullptr) {
+    if (sp.wbits != nullptr) {
         __shared__ float th_s[kWaves];
         const int tiles = 1 << (sp.log_n2 - kColsLog);
         const long long b0 = a / sp.hop, b1 = (b - 1) / sp.hop;
