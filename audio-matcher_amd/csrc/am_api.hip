@@ -330,7 +330,14 @@ static int pick_log_n(size_t s, long long out_count, const Opts& o, int* logN_ou
     if (span > (1ll << 19)) {
         // measured crossover (tools/needle_sweep.py)
         if ((long long)s <= kWideFromSamples) { *logN_out = 21; return AM_OK; }
-        if ((long long)s <= (1ll << 22) - (1ll << 20)) { *logN_out = 22; return AM_OK; }
+        if ((long long)s <= (1ll << 22) - (1ll << 20)) {
+            // a short haystack (BASELINE configs[0]: one 60 s window) whose scores fit ONE pair of 2^21
+            // blocks does not pay for a pair of 2^22 (half the points, same number of launches)
+            long long hop21 = (1ll << 21) - (long long)s + 1;
+            if (hop21 >= 8 * kTile) hop21 = (hop21 / kTile) * kTile;
+            *logN_out = (hop21 > 0 && out_count <= 2 * hop21) ? 21 : 22;
+            return AM_OK;
+        }
     }
     int pref = min_log;
     while (pref < kLogNMax) {
@@ -405,6 +412,10 @@ struct ScanRequest {
     // everything).  Used to redo single chunks with theta = -inf in place.
     long long range_a, range_b;
     int* bad;                // in: host-visible word the summary kernels of the pick set when a score is not finite, or null
+    // in (streaming ingest): summary / flag buffers owned by the caller instead of the context's sets, and
+    // "launch nothing" (every pair was computed while the samples arrived; only describe what is there)
+    DevBuf* ext_stats32; DevBuf* ext_side;
+    bool skip_launch;
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
@@ -503,8 +514,8 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         scan_req->fused = false;
         scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, (int)hop, pl->dev.logN2, pl->dev.logN1, 1.0 / (double)hop};
         if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
-            DevBuf& b32 = scan_req->set ? c->stats32_b : c->stats32;
-            DevBuf& bwf = scan_req->set ? c->wflags_b : c->wflags;
+            DevBuf& b32 = scan_req->ext_stats32 ? *scan_req->ext_stats32 : (scan_req->set ? c->stats32_b : c->stats32);
+            DevBuf& bwf = scan_req->ext_side ? *scan_req->ext_side : (scan_req->set ? c->wflags_b : c->wflags);
             if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
             if ((rc = bwf.ensure(sparse_bytes(nblocks, pl->dev)))) return rc;
             fill_scan_cfg(&scan, b32.p, bwf.p, nblocks, pl->dev, scan_req->margin, scan_req->hist_min, scan_req->seg_c, scan_req->seg_d);
@@ -520,6 +531,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
     job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
+    if (scan_req && scan_req->skip_launch) return AM_OK;
     long long pair_lo = 0, pair_hi = npairs;
     if (scan_req && scan_req->range_b > scan_req->range_a) {
         pair_lo = (scan_req->range_a / hop) / 2;
@@ -765,6 +777,14 @@ static inline const void* advance_src(const void* src, size_t elements) {
     return static_cast<const char*>(src) + 4 * elements;
 }
 
+// Streaming ingest (am_match_stream_*): the block pairs [0, pairs_done) of the one haystack were
+// computed while its samples arrived, into buffers the stream object owns.
+struct StreamPre {
+    float* scores;
+    DevBuf* stats32; DevBuf* side;
+    long long pairs_done;
+};
+
 // calc_chunks (audio_matcher.rs:88-141) over a batch of resident haystacks =
 // the per-file loop of matcher::run (matcher/mod.rs:42-87).  Everything is
 // queued on the context's stream without host synchronisation; the per-chunk
@@ -823,7 +843,7 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
 
 static int match_many(am_needle* h, const void* const* d_hays, const size_t* lens, size_t n_hay,
                       const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0,
-                      size_t index_base = 0, size_t index_stride = 1, bool fire_hooks = true) {
+                      size_t index_base = 0, size_t index_stride = 1, bool fire_hooks = true, const StreamPre* pre = nullptr) {
     Ctx* c = h->ctx;
     const Opts o = snapshot_opts(h);
     const Hooks hooks = fire_hooks ? snapshot_hooks() : Hooks{};
@@ -934,6 +954,17 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         scan.set = set;
         scan.before_k3 = (overlap && seq >= 2) ? c->ev_pick[set] : nullptr;
         scan.bad = (src_kind == 0 && std::isfinite(factor)) ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
+        if (pre) {
+            // the pairs that were computed while the samples arrived are in the stream's own buffers:
+            // only the rest is launched now, into the same buffers
+            Geometry g{};
+            if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
+            d_scores = pre->scores;
+            scan.ext_stats32 = pre->stats32; scan.ext_side = pre->side;
+            scan.range_a = std::min(pre->pairs_done, g.npairs) * 2 * g.hop;
+            scan.range_b = out_count;
+            scan.skip_launch = scan.range_a >= out_count;
+        }
         if ((rc = run_correlation(h, o, d_hays[k], (long long)lens[k], 0, d_scores, out_count, factor,
                                   &scan, src_kind))) return rc;
         if (overlap) {
@@ -950,6 +981,8 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     scan.set = 0;
     scan.before_k3 = nullptr;
     scan.bad = nullptr;
+    scan.ext_stats32 = nullptr; scan.ext_side = nullptr; scan.skip_launch = false;   // (the single-chunk passes below work in the context's own buffers)
+    scan.range_a = 0; scan.range_b = 0;
     int worst = AM_OK;
     std::vector<am_peak> all;
     const int spare_hdr = (int)nsegs;
@@ -1331,6 +1364,52 @@ struct am_pool {
 };
 
 
+// ---------------------------------------------------------------------------
+// Streaming ingest: calc_chunks consumes a lazy ExactSizeIterator (audio_matcher.rs:88-97; the
+// windows are cut as the decoder yields frames, :104, mp3_reader.rs:13-41).  The stream object owns
+// the haystack's device buffer and a set of score-side buffers; am_match_stream_push copies a block
+// of samples on a copy stream and launches K1 / K2 / K3 for every block pair whose samples have
+// arrived completely, so transfer (or decoding) and transforms overlap.
+struct am_stream {
+    am_needle* h = nullptr;
+    int fmt = AM_FMT_F32_MONO;
+    am_match_params p{};
+    am::DevBuf hay, scores, stats32, side;
+    size_t cap = 0, len = 0;          // elements (f32 samples or stereo frames, 4 bytes each)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied = nullptr;
+    bool early = false;               // block pairs may be launched before the length is known
+    long long pairs_done = 0;
+    am::Geometry geo{};               // the provisional block layout (from the capacity)
+    bool failed = false;
+};
+
+namespace am {
+
+// (re)computes the provisional layout for the stream's capacity and sizes its score-side buffers
+static int stream_layout(am_stream* st) {
+    am_needle* h = st->h;
+    const Opts o = snapshot_opts(h);
+    st->early = false;
+    st->pairs_done = 0;
+    if (st->cap < h->n || st->p.scale == AM_SCALE_MY || st->p.chunk == 0) return AM_OK;
+    if (h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0) return AM_OK;               // direct summation: no blocks
+    if (o.log_n == 0 && (long long)h->n > (1ll << 22) - (1ll << 20)) return AM_OK;    // the plan depends on the final length
+    const long long out_cap = (long long)(st->cap - h->n + 1);
+    int rc = plan_geometry(h->n, out_cap, o, &st->geo);
+    if (rc) return rc;
+    const Plan* pl = nullptr;
+    if ((rc = get_plan(h->ctx, st->geo.logN, &pl))) return rc;
+    if (!(plan_has_scan(pl->dev) && (st->geo.hop % kTile) == 0)) return AM_OK;           // (small generic plans: nothing to overlap)
+    if ((rc = st->scores.ensure((size_t)out_cap * sizeof(float)))) return rc;
+    if ((rc = st->stats32.ensure((size_t)((out_cap + 31) / 32) * sizeof(float2)))) return rc;
+    if ((rc = st->side.ensure(sparse_bytes(st->geo.nblocks, pl->dev)))) return rc;
+    st->early = true;
+    return AM_OK;
+}
+
+}  // namespace am
+
 // ===========================================================================
 extern "C" {
 
@@ -1529,6 +1608,139 @@ int am_match_multi_batch_device(const am_needle* const* needles, size_t n_needle
     std::lock_guard<std::recursive_mutex> lk(h0->ctx->mu);
     return match_multi_many(const_cast<am_needle* const*>(needles), n_needles, d_haystacks, lens, n_hay, sample_format, p,
                             out, cap_per_pair, n_out);
+}
+
+// ---- streaming ingest -------------------------------------------------------------------
+int am_match_stream_begin(const am_needle* hc, int sample_format, size_t expected_len, const am_match_params* p, am_stream** out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!p || !out) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (sample_format != AM_FMT_F32_MONO && sample_format != AM_FMT_S16_STEREO) return fail(AM_ERR_INVALID_ARG, "bad sample format");
+    if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
+    if (p->scale < AM_SCALE_NONE || p->scale > AM_SCALE_MY) return fail(AM_ERR_INVALID_ARG, "bad scale");
+    Ctx* c = h->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    am_stream* st = new am_stream();
+    st->h = h; st->fmt = sample_format; st->p = *p;
+    if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&st->copied, hipEventDisableTiming) != hipSuccess) {
+        am_match_stream_destroy(st);
+        return fail(AM_ERR_HIP, "hipStreamCreate(stream ingest)");
+    }
+    // the size hint of the reference's iterator (mp3_duration x sample rate, matcher/mod.rs:77-83) may be off
+    // by a little: leave room, so that a slightly longer file does not force a new layout
+    st->cap = expected_len ? expected_len + expected_len / 64 + 65536 : 0;
+    if (st->cap) {
+        if ((rc = st->hay.ensure(st->cap * 4)) || (rc = stream_layout(st))) { const std::string keep = t_err; am_match_stream_destroy(st); t_err = keep; return rc; }
+    }
+    *out = st;
+    return AM_OK;
+}
+
+int am_match_stream_push(am_stream* st, const void* samples, size_t n) {
+    if (!st || !st->h || (!samples && n)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (st->failed) return fail(AM_ERR_INVALID_ARG, "stream is in a failed state: destroy it");
+    if (n == 0) return AM_OK;
+    am_needle* h = st->h;
+    int rc = check_needle(h);
+    if (rc) return rc;
+    Ctx* c = h->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (st->len + n > st->cap) {
+        // longer than announced: a larger buffer (contents moved on the device) and a new provisional layout;
+        // the pairs computed so far are computed again (the layout may differ)
+        const size_t want = std::max(st->len + n, st->cap * 2 + 65536);
+        DevBuf bigger;
+        if ((rc = bigger.ensure(want * 4))) { st->failed = true; return rc; }
+        hipError_t e = hipStreamSynchronize(st->copy_stream);
+        if (e == hipSuccess && st->len) e = copy_on_stream(c, bigger.p, st->hay.p, st->len * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { bigger.release(); st->failed = true; return hip_fail(e, "stream ingest: grow"); }
+        st->hay.release();
+        st->hay = bigger;
+        st->cap = want;
+        if ((rc = stream_layout(st))) { st->failed = true; return rc; }
+    }
+    hipError_t e = hipMemcpyAsync(static_cast<char*>(st->hay.p) + st->len * 4, samples, n * 4, hipMemcpyHostToDevice, st->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(st->copied, st->copy_stream);
+    if (e != hipSuccess) { st->failed = true; return hip_fail(e, "stream ingest: copy"); }
+    st->len += n;
+    if (!st->early) { AM_HIP(hipStreamSynchronize(st->copy_stream)); return AM_OK; }
+    // pairs whose two blocks lie completely inside what has arrived: K1 reads [2q hop, (2q + 1) hop + N)
+    const Geometry& g = st->geo;
+    const long long have = (long long)st->len;
+    long long ready = have >= g.hop + g.N ? ((have - g.N) / g.hop - 1) / 2 + 1 : 0;
+    ready = std::min(ready, g.npairs);
+    if (ready - st->pairs_done < 1) { AM_HIP(hipStreamSynchronize(st->copy_stream)); return AM_OK; }
+    const Opts o = snapshot_opts(h);
+    Geometry now{};
+    if ((rc = plan_geometry(h->n, (long long)(st->cap - h->n + 1), o, &now))) return rc;
+    if (now.logN != g.logN || now.hop != g.hop) {   // an option changed under the stream: start over at finish
+        st->early = false; st->pairs_done = 0;
+        AM_HIP(hipStreamSynchronize(st->copy_stream));
+        return AM_OK;
+    }
+    ScanRequest scan{};
+    scan.margin = (!o.dense && st->p.min_prominence > 0.f) ? 0.5f * st->p.min_prominence : -1.0f;
+    scan.hist_min = h->hist_min(st->p.scale == AM_SCALE_LIB ? 1 : 0);
+    scan.seg_c = (long long)st->p.chunk;
+    scan.seg_d = (long long)(st->p.chunk + st->p.overlap) - (long long)h->n;
+    scan.ext_stats32 = &st->stats32; scan.ext_side = &st->side;
+    scan.range_a = st->pairs_done * 2 * g.hop;
+    scan.range_b = ready * 2 * g.hop;
+    AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));   // the kernels read what this push has copied
+    rc = run_correlation(h, o, st->hay.p, (long long)st->cap, 0, (float*)st->scores.p, (long long)(st->cap - h->n + 1),
+                         scale_factor(h, st->p.scale, 1), &scan, st->fmt);
+    if (rc) { st->failed = true; return rc; }
+    st->pairs_done = ready;
+    // the caller may reuse `samples` as soon as this returns
+    AM_HIP(hipStreamSynchronize(st->copy_stream));
+    return AM_OK;
+}
+
+int am_match_stream_finish(am_stream* st, am_peak* out, size_t cap, size_t* n_out) {
+    if (!st || !st->h || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (st->failed) return fail(AM_ERR_INVALID_ARG, "stream is in a failed state: destroy it");
+    am_needle* h = st->h;
+    int rc = check_needle(h);
+    if (rc) return rc;
+    Ctx* c = h->ctx;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    *n_out = 0;
+    const size_t len = st->len;
+    rc = AM_OK;
+    if (len) {
+        AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));
+        const void* src = st->hay.p;
+        StreamPre pre{(float*)st->scores.p, &st->stats32, &st->side, st->pairs_done};
+        bool use_pre = st->early && st->pairs_done > 0;
+        if (use_pre) {
+            // the layout the whole haystack gets must be the one the early pairs were computed in
+            Geometry fin{};
+            const Opts o = snapshot_opts(h);
+            if (len < h->n || plan_geometry(h->n, (long long)(len - h->n + 1), o, &fin) || fin.logN != st->geo.logN || fin.hop != st->geo.hop)
+                use_pre = false;
+        }
+        rc = match_many(h, &src, &len, 1, &st->p, out, cap, n_out, st->fmt, 0, 1, true, use_pre ? &pre : nullptr);
+    }
+    // ready for the next file of the same (announced) size
+    st->len = 0; st->pairs_done = 0;
+    return rc;
+}
+
+void am_match_stream_destroy(am_stream* st) {
+    if (!st) return;
+    if (st->h && st->h->ctx) {
+        std::lock_guard<std::recursive_mutex> lk(st->h->ctx->mu);
+        (void)hipSetDevice(st->h->ctx->device);
+        if (st->copy_stream) (void)hipStreamSynchronize(st->copy_stream);
+        (void)hipStreamSynchronize(st->h->ctx->stream);
+        st->hay.release(); st->scores.release(); st->stats32.release(); st->side.release();
+    }
+    if (st->copied) (void)hipEventDestroy(st->copied);
+    if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
+    delete st;
 }
 
 // ---- the same three entry points on interleaved i16 stereo PCM: the down-mix of

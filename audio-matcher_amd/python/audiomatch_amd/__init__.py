@@ -148,6 +148,10 @@ _SIGNATURES = {
     "am_pool_match_multi_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
                                                    C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
                                                    C.POINTER(C.c_size_t)]),
+    "am_match_stream_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(AmMatchParams), C.POINTER(C.c_void_p)]),
+    "am_match_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "am_match_stream_finish": (C.c_int, [C.c_void_p, C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_match_stream_destroy": (None, [C.c_void_p]),
     "am_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "am_profile_reset": (C.c_int, [C.c_int]),
     "am_profile_query": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -424,6 +428,39 @@ class HipConvolve:
         _check(lib().am_match_batch_device(self._h, arr_p, arr_l, k, C.byref(params), buf,
                                            cap_per_hay, counts))
         return _split_batch(buf, counts, k, cap_per_hay)
+
+
+class MatchStream:
+    """calc_chunks on a haystack that arrives in pieces (am_match_stream_*): the reference's lazy
+    sample iterator (audio_matcher.rs:88-97, mp3_reader.rs:13-41)."""
+
+    def __init__(self, algo: "HipConvolve", params: AmMatchParams, expected_len: int = 0, fmt: int = Fmt.F32_MONO):
+        self._algo = algo                      # keeps the needle handle alive
+        self.fmt = int(fmt)
+        self._s = C.c_void_p()
+        _check(lib().am_match_stream_begin(algo._h, self.fmt, int(expected_len), C.byref(params), C.byref(self._s)))
+
+    def push(self, samples):
+        a = np.ascontiguousarray(samples, dtype=np.float32 if self.fmt == Fmt.F32_MONO else np.int16)
+        n = a.size if self.fmt == Fmt.F32_MONO else a.size // 2
+        _check(lib().am_match_stream_push(self._s, a.ctypes.data, n))
+
+    def finish(self, cap: int = 4096):
+        buf = (AmPeak * cap)()
+        n = C.c_size_t(0)
+        _check(lib().am_match_stream_finish(self._s, buf, cap, C.byref(n)))
+        return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n.value]]
+
+    def close(self):
+        if getattr(self, "_s", None):
+            lib().am_match_stream_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _split_batch(buf, counts, k: int, cap: int):

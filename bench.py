@@ -72,6 +72,9 @@ def plan_geometry(s: int, h: int, log_n: int = 0):
     plan_geometry): transform length, hop, blocks, pairs."""
     if not log_n:
         log_n = 21 if s <= 300000 else 22
+        hop21 = (2 ** 21 - s + 1) // 1024 * 1024
+        if log_n == 22 and 0 < h - s + 1 <= 2 * hop21:     # a short haystack: one pair of 2^21 blocks is enough
+            log_n = 21
     n_fft = 2 ** log_n
     hop = n_fft - s + 1
     if hop >= 8192:
@@ -732,6 +735,21 @@ def side_measurements(am, device, algo, needle, params, hays, s, h, steps):
     assert [p.start for p in pk] == plant_offsets(k0)
     out["end_to_end_host_buffer"] = {"value": h / te, "unit": "samples/s",
                                      "note": "am_match from pageable host memory: H2D copy + match, 1 haystack (PCIe-bound)"}
+    # (3b) the same haystack pushed in 32 MB pieces (am_match_stream_*): the transforms of the block pairs that
+    # have arrived run beside the copy of the next piece
+    st = am.MatchStream(algo, params, h)
+    piece = 8 << 20
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for off in range(0, h, piece):
+            st.push(host[off:off + piece])
+        pk = st.finish()
+        te = time.perf_counter() - t0
+    assert [p.start for p in pk] == plant_offsets(k0)
+    st.close()
+    out["end_to_end_stream_push"] = {"value": h / te, "unit": "samples/s",
+                                     "note": "am_match_stream_begin / push (8 M samples per push from pageable host memory) / finish: "
+                                             "every block pair is transformed as soon as its samples have arrived"}
     # (4) the same through the pool (copy of haystack i+1 overlapped with the match of i)
     pool = am.Pool(needle.to_numpy("float32", s), [device])
     batch = [host, host, host, host]

@@ -185,6 +185,23 @@ int am_match_pcm16_batch_device(const am_needle* h, const int16_t* const* d_inte
                                 size_t n_hay, const am_match_params* p,
                                 am_peak* out, size_t cap_per_hay, size_t* n_out);
 
+/* ---- streaming ingest ---------------------------------------------------------- */
+/* calc_chunks consumes a lazy ExactSizeIterator<Item = f32> (audio_matcher.rs:88-97): the decoder
+ * yields frames (mp3_reader.rs:13-41) and the windows are cut as they arrive (:104).  The same
+ * here: begin a stream (expected_len = the iterator's size hint, mp3_duration x sample rate,
+ * matcher/mod.rs:77-83; 0 = unknown), push blocks of `sample_format` samples from host memory as
+ * the decoder produces them, finish.  Every push is copied on a copy stream and the transforms of
+ * every block pair whose samples have arrived completely are launched at once, so copying (or
+ * decoding) and matching overlap; finish runs what is left, picks the peaks and returns exactly
+ * what am_match / am_match_pcm16 return for the concatenated samples, bit for bit.  After finish
+ * the stream is empty again and can take the next file.  One producer per stream; streams on one
+ * device share its queue. */
+typedef struct am_stream am_stream;
+int am_match_stream_begin(const am_needle* h, int sample_format, size_t expected_len, const am_match_params* p, am_stream** out);
+int am_match_stream_push(am_stream* st, const void* samples, size_t n);
+int am_match_stream_finish(am_stream* st, am_peak* out, size_t cap, size_t* n_out);
+void am_match_stream_destroy(am_stream* st);
+
 /* find_peaks(y_data, sr, PeakConfig) (audio_matcher.rs:221-230) =
  * PeakFinder::new(y).with_min_prominence(p).with_min_distance(d).find_peaks()
  * on one host score array; peaks come back by descending height. */

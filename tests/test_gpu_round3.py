@@ -227,7 +227,7 @@ def test_pool_pcm16_equals_single_calls(gpu, oracle):
     s = 2 * sr
     needle_lr = rng.integers(-9000, 9000, size=2 * s).astype(np.int16)
     hays = []
-    for secs, ts in ((90, (10.0, 61.5)), (0, ()), (35, (20.0,)), (1, ()), (120, (5.0, 50.0, 110.0))):
+    for secs, ts in ((90, (10.0, 61.5)), (0, ()), (35, (21.0,)), (1, ()), (120, (5.0, 50.0, 110.0))):
         h = rng.integers(-9000, 9000, size=2 * secs * sr).astype(np.int32)
         for t in ts:
             off = int(t * sr)
@@ -308,3 +308,117 @@ def test_nan_in_the_rounding_slack_and_peak_at_window_end(gpu, oracle, plan):
     for _ in range(2):
         assert_same(algo.match(bad, p), exp_bad)
     assert_same(algo.match(hay, p), exp_clean)
+
+
+# ---------------------------------------------------------------------------
+# streaming ingest
+# ---------------------------------------------------------------------------
+def push_ragged(stream, data, sizes, per=1):
+    """Push `data` in pieces of the given sizes (in elements; the last size repeats)."""
+    off, i = 0, 0
+    n = data.size // per
+    while off < n:
+        k = min(sizes[min(i, len(sizes) - 1)], n - off)
+        stream.push(data[per * off:per * (off + k)])
+        off += k
+        i += 1
+
+
+def test_stream_ingest_equals_am_match(gpu, oracle):
+    """am_match_stream_begin / push / finish (calc_chunks on the reference's lazy sample iterator,
+    audio_matcher.rs:88-104, mp3_reader.rs:13-41): ragged pushes give am_match's result bit for bit --
+    with the length announced (block pairs are transformed while later samples arrive), announced
+    too short (the buffer grows and the early pairs are computed again), unknown, on a haystack too
+    short for any early pair, on a forced generic plan; the stream object is reused for a second file."""
+    sr = 8000
+    s = 2 * sr
+    needle = oracle.synth_uniform(61, 0, 0, s)
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=2.0, distance_s=30.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+
+    def make(secs, plants, seed):
+        hay = oracle.synth_uniform(seed, 1, 0, secs * sr)
+        for t in plants:
+            off = int(t * sr)
+            hay[off:off + s] += needle
+        return hay
+
+    long_hay = make(1150, (17.0, 300.5, 519.9, 520.1, 1000.0, 1147.5), 62)      # 9.2 M samples: five blocks of the 2^21 plan
+    other = make(1100, (1.0, 777.0), 63)
+    short = make(100, (13.0, 81.0), 64)
+    want = {id(h): key(algo.match(h, p)) for h in (long_hay, other, short)}
+    exp = oracle.calc_chunks(sr, long_hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+    assert [e[0] for e in exp] == [q[0] for q in want[id(long_hay)]]
+    for expected_len in (long_hay.size, 5000000, 0):
+        st = gpu.MatchStream(algo, p, expected_len)
+        push_ragged(st, long_hay, [1, 999, 1234567, 3000001, 77, 2500000])
+        assert key(st.finish()) == want[id(long_hay)], expected_len
+        push_ragged(st, other, [4000000, 123])                  # reuse: the next file
+        assert key(st.finish()) == want[id(other)], expected_len
+        push_ragged(st, short, [100000])
+        assert key(st.finish()) == want[id(short)], expected_len
+        assert st.finish() == []                                 # nothing pushed
+        st.close()
+    # early pairs really ran in the announced case: the K1 launches of a stream equal those of am_match
+    gpu.set_option("profile_mask", -1)
+    with gpu.Profile(0) as prof:
+        st = gpu.MatchStream(algo, p, long_hay.size)
+        push_ragged(st, long_hay, [3000000])
+        after_push = prof.query("k1_cols_fwd")[1]
+        res = st.finish()
+        total = prof.query("k1_cols_fwd")[1]
+        st.close()
+    assert key(res) == want[id(long_hay)] and after_push >= 1 and total > after_push
+    # a forced generic plan (no early pairs) and MyConvolve scaling go through finish alone
+    forced = gpu.HipConvolve(needle)
+    forced.set_option("log_n", 17)
+    st = gpu.MatchStream(forced, p, short.size)
+    push_ragged(st, short, [33333])
+    assert key(st.finish()) == key(forced.match(short, p))
+    st.close()
+    pm = gpu.Config(chunk_size_s=60.0, overlap_length_s=2.0, distance_s=30.0, prominence=1e-7).params(sr, gpu.Scale.MY)
+    st = gpu.MatchStream(algo, pm, short.size)
+    push_ragged(st, short, [50000])
+    assert key(st.finish()) == key(algo.match(short, pm))
+    st.close()
+
+
+def test_stream_ingest_pcm16(gpu, oracle):
+    """The same on interleaved i16 stereo frames, the format the decoder yields (mp3_reader.rs:26-37)."""
+    sr = 16000
+    rng = np.random.default_rng(17)
+    s = 2 * sr
+    needle_lr = rng.integers(-9000, 9000, size=2 * s).astype(np.int16)
+    h = rng.integers(-9000, 9000, size=2 * 560 * sr).astype(np.int32)       # 9 M frames
+    for t in (10.0, 333.3, 555.0):
+        off = int(t * sr)
+        h[2 * off:2 * (off + s)] += needle_lr
+    hay = np.clip(h, -32768, 32767).astype(np.int16)
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=2.0, distance_s=30.0, prominence=0.4).params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve.from_pcm16(needle_lr)
+    want = key(algo.match_pcm16(hay, p))
+    assert [q[0] for q in want] == [int(t * sr) for t in (10.0, 333.3, 555.0)]
+    st = gpu.MatchStream(algo, p, hay.size // 2, fmt=gpu.Fmt.S16_STEREO)
+    push_ragged(st, hay, [1152, 1152 * 1000, 2000001], per=2)       # MP3 frames are 1152 samples
+    assert key(st.finish()) == want
+    st.close()
+    with pytest.raises(gpu.AudioMatchError):
+        gpu.MatchStream(algo, p, 10, fmt=5)
+
+
+def test_short_haystack_takes_the_small_plan(gpu, oracle):
+    """BASELINE configs[0] (10 s needle, one 60 s window): the scores fit one pair of 2^21 blocks, so the
+    library does not run a pair of 2^22 (half the points); the result equals the checker's and the
+    forced 2^22 plan's offsets."""
+    sr = 44100
+    needle = oracle.synth_uniform(71, 0, 0, 10 * sr)
+    hay = oracle.synth_uniform(71, 1, 0, 60 * sr)
+    hay[20 * sr:30 * sr] += needle
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=480.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 480.0)
+    algo = gpu.HipConvolve(needle)
+    got = algo.match(hay, p)
+    assert_same(got, exp)
+    wide = gpu.HipConvolve(needle)
+    wide.set_option("log_n", 22)
+    assert pos(wide.match(hay, p)) == pos(got) == [(20 * sr, 20 * sr + 1)]
