@@ -79,6 +79,12 @@ static const int kLogNMin = 10, kLogNMax = 23;
 // needles longer than this run on N = 2^22 (measured crossover between 4 and 7 s of 44.1 kHz
 // audio, tools/needle_sweep.py, profiles/r02/needle_sweep.txt)
 static const long long kWideFromSamples = 300000;
+// Needles longer than this (the longest the 2^22 plan takes) are cut into segments of at most 2^21 samples:
+// corr(hay, needle)[j] = sum_i corr(hay, segment_i)[j + offset_i], every segment on the register kernels,
+// the partial sums added up in the score array by K3 (MyConvolve::correlate accepts any length,
+// audio_matcher.rs:414-457).
+static const long long kSegmentFrom = (1ll << 22) - (1ll << 20);
+static const long long kSegmentLen = 1ll << 21;
 
 // ---------------------------------------------------------------------------
 struct DevBuf {
@@ -296,6 +302,11 @@ struct am_needle {
     }
     // per-handle overrides of the process-wide option defaults (-1 = follow the default)
     long long opt_log_n = -1, opt_half = -1;
+    // Needle partitioning (needles longer than kSegmentFrom samples): sub-handles over slices of d_needle
+    // (not owned), each with its own spectra; segment i starts at sample seg_off[i] of the needle.
+    std::vector<am_needle*> segments;
+    std::vector<long long> seg_off;
+    bool owns_data = true;
 };
 
 namespace am {
@@ -315,7 +326,7 @@ static int pick_log_n(size_t s, long long out_count, const Opts& o, int* logN_ou
     // smallest transform that can hold the needle at all
     int min_log = kLogNMin;
     while (min_log <= kLogNMax && ((size_t)1 << min_log) < s + 1) ++min_log;
-    if (min_log > kLogNMax) return fail(AM_ERR_INVALID_ARG, "needle too long for the largest transform (2^23)");
+    if (min_log > kLogNMax) return fail(AM_ERR_INVALID_ARG, "needle too long for a forced transform size (2^23 at most; leave log_n at 0 for needle partitioning)");
     if (o.log_n > 0) {
         int l = (int)o.log_n;
         if (l < min_log) l = min_log;
@@ -416,6 +427,7 @@ struct ScanRequest {
     // "launch nothing" (every pair was computed while the samples arrived; only describe what is there)
     DevBuf* ext_stats32; DevBuf* ext_side;
     bool skip_launch;
+    bool no_scan;            // in: only the block restriction (range_a, range_b) applies; K3 writes plain scores
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
@@ -481,9 +493,62 @@ static SparseScores sparse_view(const ScanCfg& cfg, long long hop, const PlanDev
     return SparseScores{cfg.wbits, cfg.stats32, cfg.tile_theta, (int)hop, pl.logN2, pl.logN1, 1.0 / (double)hop};
 }
 
+static bool needle_is_segmented(const am_needle* h, const Opts& o) {
+    return (long long)h->n > kSegmentFrom && o.log_n == 0;
+}
+static int needle_segments(am_needle* h) {
+    if (!h->segments.empty()) return AM_OK;
+    const long long n = (long long)h->n;
+    const long long nseg = (n + kSegmentLen - 1) / kSegmentLen;
+    for (long long i = 0; i < nseg; ++i) {
+        const long long a = n * i / nseg, b = n * (i + 1) / nseg;
+        am_needle* sub = new am_needle();
+        sub->ctx = h->ctx; sub->d_needle = h->d_needle + a; sub->n = (size_t)(b - a);
+        sub->inv_autocorr = h->inv_autocorr; sub->owns_data = false;
+        h->segments.push_back(sub);
+        h->seg_off.push_back(a);
+    }
+    return AM_OK;
+}
+
+static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
+                               float* d_dst, long long out_count, float factor,
+                               ScanRequest* scan_req, int src_kind, bool accumulate);
+
+// The overlap-save engine for any needle length: one pass, or one pass per needle segment with the
+// source shifted by the segment's offset and K3 adding up the partial sums (the last pass carries
+// the fused scan, over the sums; every run is written).
 static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
                            ScanRequest* scan_req = nullptr, int src_kind = 0) {
+    if (!needle_is_segmented(h, o)) return run_correlation_one(h, o, d_src, src_len, lead, d_dst, out_count, factor, scan_req, src_kind, false);
+    int rc = needle_segments(h);
+    if (rc) return rc;
+    if (scan_req && scan_req->skip_launch) return fail(AM_ERR_INVALID_ARG, "internal: streaming ingest does not run early pairs for partitioned needles");
+    Opts os = o;
+    os.half = 0;   // (the accumulating K3 exists for the f32 work matrix)
+    const size_t nseg = h->segments.size();
+    for (size_t i = 0; i < nseg; ++i) {
+        ScanRequest* sr = nullptr;
+        ScanRequest plain{};
+        if (i + 1 == nseg && scan_req) { scan_req->margin = -1.0f; sr = scan_req; }
+        else if (scan_req) {
+            // a pass without the scan still honours the restriction to the blocks of one chunk, and the
+            // first one may not touch the score buffer before the pick that last read it is done
+            plain.margin = -1.0f; plain.range_a = scan_req->range_a; plain.range_b = scan_req->range_b;
+            plain.before_k3 = i == 0 ? scan_req->before_k3 : nullptr;
+            plain.no_scan = true;
+            sr = &plain;
+        }
+        if ((rc = run_correlation_one(h->segments[i], os, d_src, src_len, lead - h->seg_off[i], d_dst, out_count, factor, sr, src_kind, i > 0)))
+            return rc;
+    }
+    return AM_OK;
+}
+
+static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
+                               float* d_dst, long long out_count, float factor,
+                               ScanRequest* scan_req, int src_kind, bool accumulate) {
     Ctx* c = h->ctx;
     if (h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0) {
         // tiny needle: direct summation, every score written, no fused scan
@@ -510,7 +575,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     if (ppg > npairs) ppg = npairs;
     if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
     ScanCfg scan{};
-    if (scan_req) {
+    if (scan_req && !scan_req->no_scan) {
         scan_req->fused = false;
         scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, (int)hop, pl->dev.logN2, pl->dev.logN1, 1.0 / (double)hop};
         if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
@@ -545,7 +610,7 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre)); }
         if (!waited && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
         waited = true;
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, hs.level)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, hs.level, accumulate)); }
     }
     return AM_OK;
 }
@@ -810,7 +875,8 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
         ranges.push_back(Segment{segs[i].a, std::min<long long>((long long)len, segs[i].b + s - 1)});
     Geometry g{};
     long long npairs = 0;
-    if (!(h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0)) {   // (direct summation spreads nothing)
+    const bool segmented = needle_is_segmented(h, o);   // (every segment pass has block pairs of its own: all clean windows again)
+    if (!segmented && !(h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0)) {   // (direct summation spreads nothing)
         int rc = plan_geometry(h->n, out_count, o, &g);
         if (rc) return rc;
         npairs = g.npairs;
@@ -834,6 +900,7 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
     AM_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < nch; ++i) {
         if (flags[i]) { (*drop)[i] = 1; continue; }
+        if (segmented) { (*again)[i] = 1; continue; }
         const Segment sg = segs[s0 + i];
         for (long long q = 0; q < npairs && !(*again)[i]; ++q)
             if (flags[nch + q] && 2 * q * g.hop < sg.b && (2 * q + 2) * g.hop > sg.a) (*again)[i] = 1;
@@ -1123,6 +1190,19 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         return fail(AM_ERR_INVALID_ARG, "am_match_multi supports AM_SCALE_NONE and AM_SCALE_LIB");
     for (size_t k = 0; k < n_hay; ++k)
         for (size_t j = 0; j < nn; ++j) n_out[G(k) * nn + j] = 0;
+    if (needle_is_segmented(h0, o)) {
+        // partitioned needles (longer than kSegmentFrom samples) share nothing here: pair by pair
+        int worst = AM_OK;
+        for (size_t k = 0; k < n_hay; ++k)
+            for (size_t j = 0; j < nn; ++j) {
+                const size_t slot = G(k) * nn + j;
+                const int rc = match_many(needles[j], &d_hays[k], &lens[k], 1, p, out ? out + slot * cap_per_pair : nullptr, cap_per_pair,
+                                          &n_out[slot], src_kind, 0, 1, false);
+                if (rc == AM_ERR_CAPACITY) worst = rc;
+                else if (rc) return rc;
+            }
+        return worst;
+    }
     const int sm = p->scale == AM_SCALE_LIB ? 1 : 0;
     // the chunk lists of every haystack, back to back, and each haystack's block layout
     std::vector<Segment> segs;
@@ -1457,9 +1537,14 @@ void am_needle_destroy(am_needle* h) {
         std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
         (void)hipSetDevice(h->ctx->device);
         (void)hipStreamSynchronize(h->ctx->stream);
+        for (am_needle* sub : h->segments) {
+            for (auto& kv : sub->spectra) (void)hipFree(kv.second);
+            for (auto& kv : sub->spectra16) (void)hipFree(kv.second);
+            delete sub;
+        }
         for (auto& kv : h->spectra) (void)hipFree(kv.second);
         for (auto& kv : h->spectra16) (void)hipFree(kv.second);
-        if (h->d_needle) (void)hipFree(h->d_needle);
+        if (h->d_needle && h->owns_data) (void)hipFree(h->d_needle);
     }
     delete h;
 }

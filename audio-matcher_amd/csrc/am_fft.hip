@@ -1111,7 +1111,9 @@ __device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan,
 // The end of K3 for one column tile: x0 / x1[brev(a)] hold the correlation values of rows
 // n1 = a * 2^HB + hi (columns col, col+1; real part = block A, imaginary part = block B):
 // scaling, fused score scan, block vote, conditional raw-score store.
-template <int HB, typename T>
+// ACC: the scores are added to what job.dst already holds (needle partitioning: the correlation with a long
+// needle is the sum of the correlations with its segments, each on a shifted source; every run is written).
+template <int HB, typename T, bool ACC = false>
 __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, const K3Edges& ed, float2* lds2,
                                           int n2_0, int out_stride, int t, long long blkA, long long blkB,
                                           float out_scale, const T (&x0)[16], const T (&x1)[16]) {
@@ -1129,6 +1131,22 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         const T v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
         sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
         sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
+    }
+    if (ACC) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
+            if (dst8 && n + 1 < limA) { const float2 o = *reinterpret_cast<const float2*>(job.dst + outA + n); sa0[a] += o.x; sa1[a] += o.y; }
+            else {
+                if (n < limA) sa0[a] += job.dst[outA + n];
+                if (n + 1 < limA) sa1[a] += job.dst[outA + n + 1];
+            }
+            if (dst8 && n + 1 < limB) { const float2 o = *reinterpret_cast<const float2*>(job.dst + outB + n); sb0[a] += o.x; sb1[a] += o.y; }
+            else {
+                if (n < limB) sb0[a] += job.dst[outB + n];
+                if (n + 1 < limB) sb1[a] += job.dst[outB + n + 1];
+            }
+        }
     }
     // which of this thread's 16 rows leave the chip as raw scores (bit a = row a * 2^HB + hi), per block
     unsigned wantA = 0xFFFFu, wantB = 0xFFFFu;
@@ -1242,6 +1260,7 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
 // k1 = hi + 16*b' (natural b' order, columns col, col+1) are in registers: conjugate
 // pipeline twiddle, inverse 256-point column FFT, then k3_finish.  Output index of row n1,
 // column c is n1 * out_stride + c.
+template <bool ACC = false>
 __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2,
                                         int n2_0, int out_stride, int t, long long blkA, long long blkB,
                                         float out_scale, float2 (&x0)[16], float2 (&x1)[16]) {
@@ -1279,7 +1298,7 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     twiddle_nat<16, true>(x1, w256);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
-    k3_finish<4>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
+    k3_finish<4, float2, ACC>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // The same with the first pass (pipeline twiddle, 16-point transform over b') and the exchange on
@@ -1326,7 +1345,7 @@ __device__ __forceinline__ void k3_tile_h16(const Job& job, const PlanDev& pl, c
 #ifndef AM_K3_WGS
 #define AM_K3_WGS 3   // waves per SIMD the register allocation has to allow (= workgroups per CU for 256 threads; it uses 118 VGPRs: four fit)
 #endif
-template <int HALF>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
+template <int HALF, bool ACC = false>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
 __global__ void __launch_bounds__(256, AM_K3_WGS)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1370,7 +1389,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
             x1[bp] = make_float2(v.z, v.w);
         }
     }
-    k3_tile(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile<ACC>(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -1521,7 +1540,7 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <int HALF>   // as in k1_cols_fwd_c512
+template <int HALF, bool ACC = false>   // as in k1_cols_fwd_c512
 __global__ void __launch_bounds__(512, 2)   // (uses 119 / 117 VGPRs: two workgroups per CU; a tighter bound makes the allocator spill)
 k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1658,7 +1677,7 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     twiddle_nat<16, true>(x1, w512);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*32 + b
     dif<16, true>(x1);
-    k3_finish<5>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_finish<5, T, ACC>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -1824,7 +1843,7 @@ k2_rows_gen(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
 
 template <int BL>
 __global__ void __launch_bounds__(kFftThreads)
-k3_cols_inv_gen(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale) {
+k3_cols_inv_gen(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, int acc) {
     extern __shared__ float2 s[];
     const int N1 = 1 << pl.logN1, N2 = 1 << pl.logN2;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1849,8 +1868,8 @@ k3_cols_inv_gen(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         const long long n = (long long)r * N2 + n2_0 + c;
         if (n >= job.hop) continue;
         const float2 v = s[idx];
-        if (outA + n < job.out_count) job.dst[outA + n] = v.x * out_scale;
-        if (validB && outB + n < job.out_count) job.dst[outB + n] = v.y * out_scale;
+        if (outA + n < job.out_count) job.dst[outA + n] = v.x * out_scale + (acc ? job.dst[outA + n] : 0.0f);
+        if (validB && outB + n < job.out_count) job.dst[outB + n] = v.y * out_scale + (acc ? job.dst[outB + n] : 0.0f);
     }
 }
 
@@ -1917,6 +1936,8 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k1_cols_fwd_c512<0, 2>), kC512Lds)
     AM_SET_LDS((k1_cols_fwd_c512<1, 2>), kC512Lds)
     AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
+    AM_SET_LDS((k3_cols_inv_c512<0, true>), kC512Lds)
+    AM_SET_LDS((k3_cols_inv_r16<0, true>), kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_c512<1>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_c512<2>, kC512Lds)
     AM_SET_LDS(k3_cols_inv_r16<0>, kR16LdsK3)
@@ -2006,9 +2027,16 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
 
 // scan.stats32 != nullptr only for the plans with a fused scan (plan_has_scan) and a 1024-aligned hop
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half) {
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half, bool accumulate) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
-    if (plan_is_c512(pl)) {
+    if (accumulate && half) return hipErrorInvalidValue;   // (the accumulating forms exist for the f32 work matrix only)
+    if (accumulate && plan_is_c512(pl)) {
+        hipLaunchKernelGGL((k3_cols_inv_c512<0, true>), dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
+                           pl, out_scale, scan);
+    } else if (accumulate && plan_is_r16(pl)) {
+        hipLaunchKernelGGL((k3_cols_inv_r16<0, true>), dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(256), kR16LdsK3, st, job, work,
+                           pl, out_scale, scan);
+    } else if (plan_is_c512(pl)) {
         if (half == 2) hipLaunchKernelGGL(k3_cols_inv_c512<2>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
                                           pl, out_scale, scan);
         else if (half) hipLaunchKernelGGL(k3_cols_inv_c512<1>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
@@ -2024,7 +2052,7 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                                 pl, out_scale, scan);
     } else {
         const size_t lds = (sizeof(float2) << pl.logN1) << kColsLog;
-        hipLaunchKernelGGL(k3_cols_inv_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl, out_scale);
+        hipLaunchKernelGGL(k3_cols_inv_gen<kColsLog>, grid, dim3(kFftThreads), lds, st, job, work, pl, out_scale, accumulate ? 1 : 0);
     }
     return hipGetLastError();
 }

@@ -78,8 +78,9 @@ struct ScanCfg {
     long long seg_c, seg_d;   // chunk geometry: runs that hold score i*seg_c or i*seg_c + seg_d are chunk edges
     double inv_c;             // 1.0 / seg_c
 };
+// accumulate: the scores are added to what job.dst holds (every run written; f32 work matrix only)
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half = 0);
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half = 0, bool accumulate = false);
 // needles of at most this many samples are correlated by direct summation (no transform)
 constexpr int kDirectMaxNeedle = 64;
 hipError_t launch_direct(hipStream_t st, const Job& job, const float* needle, int s, float out_scale);

@@ -422,3 +422,67 @@ def test_short_haystack_takes_the_small_plan(gpu, oracle):
     wide = gpu.HipConvolve(needle)
     wide.set_option("log_n", 22)
     assert pos(wide.match(hay, p)) == pos(got) == [(20 * sr, 20 * sr + 1)]
+
+
+# ---------------------------------------------------------------------------
+# long needles: needle partitioning
+# ---------------------------------------------------------------------------
+def test_needles_longer_than_the_largest_plan_are_partitioned(gpu, oracle):
+    """MyConvolve::correlate takes a needle of any length (audio_matcher.rs:414-457).  Above
+    3 145 728 samples (the longest the 2^22 plan holds) the needle is cut into segments of at most
+    2^21 samples whose correlations -- each on a source shifted by the segment's offset -- K3 adds up in
+    the score array: level 1 (all three modes) and calc_chunks against the checker, then a needle
+    above 2^23 samples, which no single transform of the library could hold."""
+    sr = 8000
+    s = 3300000                                             # 412.5 s at 8 kHz: two segments
+    needle = oracle.synth_uniform(81, 0, 0, s)
+    hay = oracle.synth_uniform(81, 1, 0, 11000000)
+    plants = [400000, 6100000]
+    for t in plants:
+        hay[t:t + s] += needle
+    algo = gpu.HipConvolve(needle)
+    inv = 1.0 / float(np.sum(needle.astype(np.float64) ** 2))
+    assert abs(algo.inverse_sample_auto_correlation() - inv) < 1e-6 * inv
+    # level 1
+    within = hay[:5000000]
+    for mode, omode in ((gpu.Mode.Valid, oracle.MODE_VALID), (gpu.Mode.Same, oracle.MODE_SAME), (gpu.Mode.Full, oracle.MODE_FULL)):
+        got = algo.correlate_with_sample(within, mode, True)
+        exp = oracle.correlate(within, needle, omode, oracle.SCALE_LIB)
+        assert got.shape == exp.shape and float(np.abs(got - exp).max()) < TOL
+    # level 2: chunks of 600 s with the needle's length as overlap (Config::from_args, audio_matcher.rs:41)
+    p = gpu.AmMatchParams(sr=sr, chunk=600 * sr, overlap=s, min_prominence=0.13, min_distance=480 * sr,
+                          overshadow_distance_s=480.0, scale=int(gpu.Scale.LIB))
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 480.0)
+    assert [e[0] for e in exp] == plants
+    for _ in range(2):
+        assert_same(algo.match(hay, p), exp)
+    buf = gpu.DeviceBuffer.from_numpy(0, hay)
+    res = algo.match_batch_device([buf.ptr, buf.ptr], [hay.size] * 2, p)
+    assert_same(res[0], exp)
+    assert key(res[0]) == key(res[1])
+    # the several-needle entry point takes such needles too (pair by pair)
+    res = gpu.match_multi_batch_device([algo, algo], [buf.ptr], [hay.size], p)
+    assert key(res[0][0]) == key(res[0][1]) and pos(res[0][0]) == [(t, t + 1) for t in plants]
+    # a stream (no early pairs for a partitioned needle) and a NaN in the haystack
+    st = gpu.MatchStream(algo, p, hay.size)
+    push_ragged(st, hay, [2500000])
+    assert_same(st.finish(), exp)
+    st.close()
+    bad = hay.copy()
+    bad[9000000] = np.nan                                   # only the second window (4.8 M .. 11 M) holds it
+    exp_bad = oracle.calc_chunks(sr, bad, needle, p.chunk, p.overlap, 0.13, p.min_distance, 480.0)
+    assert [e[0] for e in exp_bad] == plants[:1]
+    assert_same(algo.match(bad, p), exp_bad)
+    # above 2^23 samples
+    s2 = 8500000
+    needle2 = oracle.synth_uniform(82, 0, 0, s2)
+    within2 = oracle.synth_uniform(82, 1, 0, 12000000)
+    within2[1234567:1234567 + s2] += needle2
+    got = gpu.HipConvolve(needle2).correlate_with_sample(within2, gpu.Mode.Valid, True)
+    exp = oracle.correlate(within2, needle2, oracle.MODE_VALID, oracle.SCALE_LIB)
+    assert got.shape == exp.shape == (12000000 - s2 + 1,)
+    assert float(np.abs(got - exp).max()) < TOL and int(np.argmax(got)) == 1234567
+    forced = gpu.HipConvolve(needle2)
+    forced.set_option("log_n", 23)
+    with pytest.raises(gpu.AudioMatchError):
+        forced.correlate_with_sample(within2, gpu.Mode.Valid, True)
