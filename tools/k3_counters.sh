@@ -7,16 +7,18 @@ set -o pipefail
 out=${1:-gpurun_out/k3c}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 --list-avail > "$out/list_avail.txt" 2>&1
 lean="--no-cpu-baseline --no-extra-legs --no-batch-1000 --steps 1 --warmup 1 --ramp-steps 0 --haystacks-per-step 3"
 i=0
-for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum" \
-           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum" \
-           "SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY" \
-           "TCC_TAG_STALL_sum TCC_NORMAL_WRITEBACK_sum TCC_EA0_RD_UNCACHED_32B_sum TCC_BUSY_sum TA_BUSY_sum"; do
+# two counters of one hardware block per pass (five TCC counters in one pass exceed what the block can
+# collect: rocprofv3 aborts and then hangs), every pass under its own time limit
+for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TCC_WRITE_sum TCC_TAG_STALL_sum" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" \
+           "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum" "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
+           "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o run -- python3 bench.py $lean > "$out/pass$i.log" 2>&1 || echo "pass $i failed (a counter name this build does not know?)" >> "$out/failed.txt"
+  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o run -- python3 bench.py $lean > "$out/pass$i.log" 2>&1 \
+    || { echo "pass $i ($set) failed or timed out" >> "$out/failed.txt"; if grep -q "caught signal" "$out/pass$i.log"; then echo "stopping: the profiler aborted" >> "$out/failed.txt"; break; fi; }
 done
 python3 - "$out" <<'PY'
 import collections, csv, glob, json, sys
@@ -40,9 +42,15 @@ for key, pat in KEYS.items():
         h, m = agg.get("TCC_HIT_sum"), agg.get("TCC_MISS_sum")
         if h is not None and m is not None and h + m > 0:
             agg["derived_l2_hit_rate"] = h / (h + m)
+        def ratio(a, b):
+            return agg[a] / agg[b] if agg.get(a) is not None and agg.get(b) else None
+        agg["derived_fabric_read_latency_cycles"] = ratio("TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_sum")
+        agg["derived_l1_to_l2_read_latency_cycles"] = ratio("TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum")
+        agg["derived_share_of_fabric_reads_from_dram"] = ratio("TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_RDREQ_sum")
+        agg["derived_vmem_in_flight_per_wave_cycle"] = ratio("SQ_INST_LEVEL_VMEM", "SQ_WAVE_CYCLES")
         res[key] = agg
 json.dump(res, open(f"{root}/cache_counters.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
-rm -rf "$out"/pass[0-9]
+find "$out" -maxdepth 1 -type d -name "pass*" -exec rm -rf {} +
 echo collected
