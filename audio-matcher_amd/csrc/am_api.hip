@@ -1020,7 +1020,8 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
         scan.set = set;
         scan.before_k3 = (overlap && seq >= 2) ? c->ev_pick[set] : nullptr;
-        scan.bad = (src_kind == 0 && std::isfinite(factor)) ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
+        // (i16 frames are always finite -- but a half-precision transform can overflow on them)
+        scan.bad = ((src_kind == 0 || o.half) && std::isfinite(factor)) ? &h_bad[k] : nullptr;
         if (pre) {
             // the pairs that were computed while the samples arrived are in the stream's own buffers:
             // only the rest is launched now, into the same buffers
@@ -1052,11 +1053,17 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     scan.range_a = 0; scan.range_b = 0;
     int worst = AM_OK;
     std::vector<am_peak> all;
+    std::vector<size_t> retry_f32;
     const int spare_hdr = (int)nsegs;
     for (size_t k = 0; k < n_hay; ++k) {
         const int s0 = seg_off[k], s1 = seg_off[k + 1];
         if (n_chunks[k] == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
+        // Non-finite scores out of a half-precision pipeline: most likely an overflow of f16's range in the
+        // row transform (a strong component that needle and haystack share, e.g. a DC offset or a steady
+        // tone, concentrates in a few bins).  The haystack is matched again in f32, after every other
+        // result of this call has been collected (the pass reuses the call's result area).
+        if (h_bad[k] && o.half) { retry_f32.push_back(k); continue; }
         if (!my && !h_bad[k] && s1 > s0) {   // (a haystack with non-finite scores teaches the threshold nothing)
             float lowest = FLT_MAX;
             for (int i = s0; i < s1; ++i) lowest = std::min(lowest, h_hdr[i].seg_min);
@@ -1155,6 +1162,17 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }   // audio_matcher.rs:126
         }
         rc = merge_peaks(all, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
+        chunk_events(k, 1);
+        if (hooks.fn) hooks.fn(hooks.user, G(k), 1, (size_t)n_chunks[k]);
+        if (rc == AM_ERR_CAPACITY) worst = rc;
+        else if (rc) return rc;
+    }
+    for (size_t k : retry_f32) {
+        const long long keep = h->opt_half;
+        h->opt_half = 0;
+        rc = match_many(h, &d_hays[k], &lens[k], 1, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)], src_kind,
+                        0, 1, false);
+        h->opt_half = keep;
         chunk_events(k, 1);
         if (hooks.fn) hooks.fn(hooks.user, G(k), 1, (size_t)n_chunks[k]);
         if (rc == AM_ERR_CAPACITY) worst = rc;
@@ -1308,7 +1326,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             scan.hist_min = h->hist_min(sm);
             scan.seg_c = (long long)p->chunk;
             scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
-            scan.bad = src_kind == 0 ? &h_bad[k] : nullptr;   // (i16 frames are always finite)
+            scan.bad = (src_kind == 0 || o.half) ? &h_bad[k] : nullptr;   // (i16 frames are always finite; an f16 transform can overflow)
             scan.fused = fused;
             scan.sparse = SparseScores{nullptr, nullptr, nullptr, (int)g.hop, pl->dev.logN2, pl->dev.logN1, 1.0 / (double)g.hop};
             ScanCfg cfg{};
@@ -1593,8 +1611,25 @@ static int correlate_impl(const am_needle* hc, const float* within, size_t w, in
         d_in = (const float*)c->io_in.p;
         d_out = (float*)c->io_out.p;
     }
-    const Opts o = snapshot_opts(h);
+    Opts o = snapshot_opts(h);
     if ((rc = run_correlation(h, o, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
+    if (o.half) {
+        // a half-precision transform can leave f16's range (see match_many): look at the result once and
+        // compute it again in f32 if it holds a non-finite value (a bad input is dealt with below)
+        const Segment whole{0, (long long)len};
+        int flag = 0;
+        if ((rc = c->ranges.ensure(sizeof(Segment)))) return rc;
+        if ((rc = c->range_flags.ensure(sizeof(int)))) return rc;
+        AM_HIP(hipMemcpyAsync(c->ranges.p, &whole, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+        AM_HIP(hipMemsetAsync(c->range_flags.p, 0, sizeof(int), c->stream));
+        AM_HIP(launch_nonfinite_ranges(c->stream, d_out, (const Segment*)c->ranges.p, 1, (int*)c->range_flags.p));
+        AM_HIP(hipMemcpyAsync(&flag, c->range_flags.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        AM_HIP(hipStreamSynchronize(c->stream));
+        if (flag) {
+            o.half = 0;
+            if ((rc = run_correlation(h, o, d_in, (long long)w, lead, d_out, (long long)len, scale_factor(h, scale, w)))) return rc;
+        }
+    }
     // A NaN or an infinity in `within` makes every output of the reference's one transform per
     // window NaN (audio_matcher.rs:414-457); overlap-save confines it to the block pairs around
     // it.  Look at the window once and give the reference's answer.

@@ -486,3 +486,38 @@ def test_needles_longer_than_the_largest_plan_are_partitioned(gpu, oracle):
     forced.set_option("log_n", 23)
     with pytest.raises(gpu.AudioMatchError):
         forced.correlate_with_sample(within2, gpu.Mode.Valid, True)
+
+
+# ---------------------------------------------------------------------------
+# half precision: leaving f16's range must not lose hits
+# ---------------------------------------------------------------------------
+def test_half_pipeline_overflow_falls_back_to_f32(gpu, oracle):
+    """A component that needle and haystack share (here a DC offset of 0.4) concentrates in a few bins of the
+    row transform and leaves f16's range at half_pipeline = 2 (tools/halfcheck.py found it on the
+    tone-and-drift signal: scores become inf and a hit is lost).  The library notices non-finite scores
+    out of a half-precision pass -- also on i16 input, whose samples are always finite -- and matches that
+    haystack again in f32: the result is the f32 result, bit for bit; level 1 (correlate) likewise."""
+    sr = 8000
+    s = 2 * sr
+    rng = np.random.default_rng(91)
+    needle = (rng.uniform(-0.25, 0.25, s) + 0.4).astype(np.float32)
+    hay = (rng.uniform(-0.25, 0.25, 300 * sr) + 0.4).astype(np.float32)
+    calm = rng.uniform(-0.25, 0.25, 300 * sr).astype(np.float32)
+    for t in (33, 170, 288):
+        hay[t * sr:t * sr + s] += needle
+        calm[t * sr:t * sr + s] += needle
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=2.0, distance_s=30.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    f32 = gpu.HipConvolve(needle)
+    want, want_calm = key(f32.match(hay, p)), f32.match(calm, p)
+    assert [q[0] for q in want] == [33 * sr, 170 * sr, 288 * sr]
+    half = gpu.HipConvolve(needle)
+    half.set_option("half_pipeline", 2)
+    raw = half.correlate_with_sample(hay, gpu.Mode.Valid, True)
+    assert np.isfinite(raw).all() and float(np.abs(raw - f32.correlate_with_sample(hay, gpu.Mode.Valid, True)).max()) == 0.0
+    assert key(half.match(hay, p)) == want
+    bufs = [gpu.DeviceBuffer.from_numpy(0, x) for x in (calm, hay, calm)]
+    res = half.match_batch_device([b.ptr for b in bufs], [hay.size] * 3, p)
+    assert key(res[1]) == want                                # redone in f32
+    for r in (res[0], res[2]):                                # stayed in half precision: offsets, heights to 2e-3
+        assert pos(r) == pos(want_calm)
+        assert all(abs(g.height - o.height) < 2e-3 for g, o in zip(r, want_calm)) and key(r) != key(want_calm)
