@@ -135,8 +135,6 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           // peak pick of haystack k beside the transforms of k+1 (batches)
-    hipStream_t stream3 = nullptr;           // several needles: the inverse column passes of a needle group beside the next group's rows
-    hipEvent_t ev_k2g[2] = {nullptr, nullptr}, ev_k3done[2] = {nullptr, nullptr};
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
     DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur, wide_ctl, wide_list, wide_tiles;
@@ -185,10 +183,7 @@ static int get_ctx(int device, Ctx** out) {
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
     (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-    (void)hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
     for (int i = 0; i < 2; ++i) {
-        (void)hipEventCreateWithFlags(&c->ev_k2g[i], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&c->ev_k3done[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_k3[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_pick[i], hipEventDisableTiming);
     }
@@ -219,7 +214,6 @@ static void prof_harvest(Ctx* c) {
     if (c->pending.empty()) return;
     (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     for (auto& r : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { c->prof_ms[r.name] += ms; c->prof_n[r.name] += 1; }
@@ -1273,13 +1267,8 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     for (size_t k = 0; k < n_hay; ++k) n_pairs_active += seg_off[k + 1] > seg_off[k] ? nn : 0;
     const bool overlap = o.batch_overlap && n_pairs_active > 1 && c->stream2 &&
                          c->ev_k3[0] && c->ev_k3[1] && c->ev_pick[0] && c->ev_pick[1];
-    // With the overlap on, three queues: the forward column pass and the row passes of needle group g + 1
-    // (arithmetic-bound) on the main stream, the inverse column passes of group g (memory-bound) on a
-    // second one, the peak picks on a third; the inverse rows alternate between two buffers.
-    const bool split = overlap && c->stream3 && c->ev_k2g[0] && c->ev_k2g[1] && c->ev_k3done[0] && c->ev_k3done[1];
-    const size_t group_slots = std::min(group_opt, nn);
     if ((rc = c->work.ensure(max_work * sizeof(float2)))) return rc;
-    if ((rc = c->work2.ensure((split ? 2 : 1) * group_slots * max_matrix * sizeof(float2)))) return rc;
+    if ((rc = c->work2.ensure(std::min(group_opt, nn) * max_matrix * sizeof(float2)))) return rc;
     for (int set = 0; set < (overlap ? 2 : 1); ++set) {
         if ((rc = (set ? c->scores_b : c->scores).ensure(max_scores * sizeof(float)))) return rc;
         if ((rc = (set ? c->peaks_b : c->peaks).ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
@@ -1299,8 +1288,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     // result headers of (haystack k, needle j): nsegs entries per needle, the haystack's slice inside
     auto hdr_of = [&](size_t k, size_t j) { return (int)(j * nsegs) + seg_off[k]; };
-    hipStream_t s_k3 = split ? c->stream3 : c->stream, s_pick = overlap ? c->stream2 : c->stream;
-    size_t seq = 0, gseq = 0;
+    size_t seq = 0;
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
@@ -1318,25 +1306,17 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         job.src = d_hays[k]; job.src_len = (long long)lens[k]; job.lead = 0; job.src_kind = src_kind;
         job.out_count = out_count; job.hop = (int)g.hop; job.nblocks = (int)g.nblocks; job.first_pair = 0;
         { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)g.npairs, (float2*)c->work.p, pl->dev, half)); }
-        float2* rows_base = nullptr;   // the inverse rows of the current group (one of the two halves of work2)
-        int gp = 0;
         for (size_t j = 0; j < nn; ++j) {
             am_needle* h = needles[j];
             const size_t in_group = j % group;
-            if (in_group == 0) {
-                // a new group: its inverse rows go to the half of work2 that the group before the last one used
-                gp = split ? (int)(gseq & 1) : 0;
-                rows_base = (float2*)c->work2.p + (size_t)gp * group_slots * max_matrix;
-                if (split && gseq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_k3done[gp], 0));
-                if (group > 1) {
-                    K2Group grp{};
-                    grp.n = (int)std::min(group, nn - j);
-                    for (int q = 0; q < grp.n; ++q) { grp.hc[q] = hc[j + q]; grp.dst[q] = rows_base + (size_t)q * matrix; }
-                    ProfScope ps(c, KN_K2);
-                    AM_HIP(launch_k2_group(c->stream, (int)g.npairs, (const float2*)c->work.p, grp, pl->dev));
-                }
+            const float2* inv_rows = (const float2*)c->work2.p + in_group * matrix;   // this needle's inverse rows
+            if (group > 1 && in_group == 0) {
+                K2Group grp{};
+                grp.n = (int)std::min(group, nn - j);
+                for (int q = 0; q < grp.n; ++q) { grp.hc[q] = hc[j + q]; grp.dst[q] = (float2*)c->work2.p + (size_t)q * matrix; }
+                ProfScope ps(c, KN_K2);
+                AM_HIP(launch_k2_group(c->stream, (int)g.npairs, (const float2*)c->work.p, grp, pl->dev));
             }
-            const float2* inv_rows = rows_base + in_group * matrix;   // this needle's inverse rows
             const int set = overlap ? (int)(seq & 1) : 0;
             float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
             job.dst = d_scores;
@@ -1359,33 +1339,21 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             const HalfScale hs = half_scale(h, o, pl->dev);
             if (group == 1) {
                 ProfScope ps(c, KN_K2);
-                AM_HIP(launch_k2(c->stream, (int)g.npairs, (float2*)c->work.p, hc[j], pl->dev, rows_base, hs.level, hs.hscale, hs.pre));
-            }
-            if (split && (group == 1 || in_group == 0)) {
-                // the inverse column passes of this group wait for its rows
-                AM_HIP(hipEventRecord(c->ev_k2g[gp], c->stream));
-                AM_HIP(hipStreamWaitEvent(s_k3, c->ev_k2g[gp], 0));
+                AM_HIP(launch_k2(c->stream, (int)g.npairs, (float2*)c->work.p, hc[j], pl->dev, (float2*)c->work2.p, hs.level, hs.hscale, hs.pre));
             }
             // K3 overwrites this set's scores and summaries: the pick that last read them must be done
-            if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(s_k3, c->ev_pick[set], 0));
-            { ProfScope ps(c, KN_K3, s_k3); AM_HIP(launch_k3(s_k3, job, (int)g.npairs, inv_rows, pl->dev, hs.k3(factor), cfg, half)); }
+            if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
+            { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, (int)g.npairs, inv_rows, pl->dev, hs.k3(factor), cfg, half)); }
             if (overlap) {
-                AM_HIP(hipEventRecord(c->ev_k3[set], s_k3));
-                AM_HIP(hipStreamWaitEvent(s_pick, c->ev_k3[set], 0));
+                AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
+                AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
             }
             if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
-                                  &scan, hdr_of(k, j), arena, s_pick))) return rc;
-            if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], s_pick));
+                                  &scan, hdr_of(k, j), arena, overlap ? c->stream2 : c->stream))) return rc;
+            if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
             ++seq;
-            const bool group_ends = in_group + 1 == group || j + 1 == nn;
-            if (group_ends) {
-                if (split) AM_HIP(hipEventRecord(c->ev_k3done[gp], s_k3));   // this half of work2 may be overwritten
-                ++gseq;
-            }
         }
-        // the next haystack's forward pass overwrites `work`: on the main stream, behind this haystack's row passes
     }
-    if (split) AM_HIP(hipStreamSynchronize(c->stream3));
     AM_HIP(hipStreamSynchronize(c->stream));
     if (overlap) AM_HIP(hipStreamSynchronize(c->stream2));
     int worst = AM_OK;
@@ -2094,7 +2062,6 @@ int am_shutdown(void) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-        if (c->stream3) (void)hipStreamSynchronize(c->stream3);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
                           &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b,
                           &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur, &c->wide_ctl, &c->wide_list, &c->wide_tiles})
