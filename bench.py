@@ -317,7 +317,8 @@ def parse_args():
     ap.add_argument("--dry-shard", action="store_true",
                     help="print every rank's shard of --total-haystacks (default 1000) and stop before any GPU work")
     ap.add_argument("--allow-shared-devices", action="store_true",
-                    help="rehearsal: let several ranks share one GPU (the line then carries n_gpus = devices actually used)")
+                    help="(accepted for older command lines) ranks that share a GPU are always allowed as a rehearsal: the line "
+                         "then reports n_gpus = devices actually used and carries a warning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the dense / non-white / host-buffer side measurements")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU sample (0 = three per thread, at most the whole hour)")
@@ -482,9 +483,9 @@ def main():
     idents = R.gather(device_identity(device))
     devices_used = len(set(idents))
     rpd = max(idents.count(i) for i in set(idents))
-    if rpd > 1 and not args.allow_shared_devices:
-        raise SystemExit(f"bench.py: {R.world} ranks but only {devices_used} distinct GPU(s) ({ndev} visible per rank): one rank per "
-                         f"GPU is the contract; pass --allow-shared-devices for a rehearsal (n_gpus then reports {devices_used})")
+    if rpd > 1 and R.rank == 0:
+        print(f"bench.py: {R.world} ranks but only {devices_used} distinct GPU(s) ({ndev} visible per rank): one rank per GPU is the "
+              f"contract -- this run is a rehearsal, its line reports n_gpus = {devices_used} and carries a warning", file=sys.stderr)
     if args.log_n:
         am.set_option("log_n", args.log_n)
     if args.half_pipeline and args.config != 4:

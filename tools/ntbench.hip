@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(256, 3) col_rw(float4* m, float* sink) {
 template <int NT, int UNROLL>
 __global__ void __launch_bounds__(256) stream_copy(const float4* __restrict__ s, float4* __restrict__ d, size_t n) {
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
         f32x4 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -88,18 +89,33 @@ __global__ void __launch_bounds__(256) stream_copy(const float4* __restrict__ s,
             if (NT) __builtin_nontemporal_store(v[u], q); else *q = v[u];
         }
     }
+    // the rest of the buffer, one access per trip: every launch moves all n elements whatever the grid
+    // (round 2's version stopped at the last full unrolled trip: with 16384 workgroups x 8 accesses a
+    // third of the buffer was never touched and the rate printed from the whole buffer exceeded 8 TB/s)
+    for (; i < n; i += stride) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(s) + i;
+        const f32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
+        f32x4* q = reinterpret_cast<f32x4*>(d) + i;
+        if (NT) __builtin_nontemporal_store(v, q); else *q = v;
+    }
 }
 template <int NT, int UNROLL>
 __global__ void __launch_bounds__(256) stream_read(const float4* __restrict__ s, float* sink, size_t n) {
     const size_t stride = (size_t)gridDim.x * 256;
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const f32x4* p = reinterpret_cast<const f32x4*>(s) + i + u * stride;
             const f32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
             acc += v.x + v.y + v.z + v.w;
         }
+    }
+    for (; i < n; i += stride) {   // the rest of the buffer (see stream_copy)
+        const f32x4* p = reinterpret_cast<const f32x4*>(s) + i;
+        const f32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
+        acc += v.x + v.y + v.z + v.w;
     }
     if (acc == 123.456f) sink[0] = acc;
 }
