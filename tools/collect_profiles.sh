@@ -1,27 +1,35 @@
 #!/bin/bash
-# Collects the evidence kept under profiles/: bench line, rocprofv3 kernel-trace stats of the same
-# command, and the two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, no trace domains).
-# Run on the GPU box from the repo root:  tools/collect_profiles.sh gpurun_out/<tag>
+# Collects the evidence kept under profiles/<round>/: the bench line of every BASELINE config, the rocprofv3
+# kernel-trace stats of the same commands, and the two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+# runs, no trace domains).  Run on the GPU box from the repo root:  tools/collect_profiles.sh gpurun_out/<tag>
 set -o pipefail
 out=${1:-gpurun_out/prof}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err" || exit 1
 lean="--no-cpu-baseline --no-extra-legs --no-batch-1000"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- python3 bench.py $lean > "$out/stats.log" 2>&1 || exit 1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$out/pmc/$c" -o run -- python3 bench.py $lean --steps 1 --warmup 1 --ramp-steps 0 --haystacks-per-step 3 > "$out/pmc_$c.log" 2>&1 || exit 1
+python3 bench.py --config 3 $lean > "$out/bench_config3.json" 2> "$out/bench_config3.err" || exit 1
+python3 bench.py --config 4 $lean > "$out/bench_config4.json" 2> "$out/bench_config4.err" || exit 1
+for cfg in 2 3 4; do
+  timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats$cfg" -o run -- python3 bench.py --config $cfg $lean > "$out/stats$cfg.log" 2>&1 || exit 1
+  find "$out/stats$cfg" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats_config$cfg.csv" \;
+  rm -rf "$out/stats$cfg"
 done
-python3 tools/pmc_summary.py "$out/pmc" "$out/pmc_traffic.json" > "$out/pmc_summary.log" 2>&1
-find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
-rm -rf "$out/stats" "$out/pmc"
+for cfg in 2 4; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 5 200 rocprofv3 --pmc $c --output-format csv -d "$out/pmc$cfg/$c" -o run -- python3 bench.py --config $cfg $lean --steps 1 --warmup 1 --ramp-steps 0 --haystacks-per-step 3 > "$out/pmc${cfg}_$c.log" 2>&1 || exit 1
+  done
+  python3 tools/pmc_summary.py "$out/pmc$cfg" "$out/pmc_traffic_config$cfg.json" > "$out/pmc_summary$cfg.log" 2>&1
+  rm -rf "$out/pmc$cfg"
+done
 for level in 1 2; do
   python3 bench.py $lean --half-pipeline $level > "$out/bench_half$level.json" 2> "$out/bench_half$level.err" || exit 1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats_h2" -o run -- python3 bench.py $lean --half-pipeline 2 > "$out/stats_h2.log" 2>&1 || exit 1
-find "$out/stats_h2" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats_half_level2.csv" \;
-rm -rf "$out/stats_h2"
 tools/sq_counters.sh "$out/sq" > /dev/null 2>&1 && cp "$out/sq/sq_counters.json" "$out/sq_counters.json"
-python3 tools/extra_bench.py > "$out/extra.json" 2> "$out/extra.err"
-python3 tools/multi_bench.py 32 8 > "$out/multi32.json" 2> "$out/multi32.err"
+[ -x tools/ntbench ] && tools/ntbench > "$out/ntbench_cache_policy.txt" 2>&1
+# two ranks sharing the one GPU of this box: a rehearsal of the rank plumbing for every config (flagged in the line)
+for cfg in 2 3 4; do
+  python3 bench.py --gpus 2 --config $cfg $lean --steps 3 --warmup 1 --ramp-steps 2 --haystacks-per-step 2 > "$out/rehearsal_2_ranks_config$cfg.json" 2> "$out/rehearsal$cfg.err"
+done
+python3 bench.py --gpus 2 --config 3 $lean --total-haystacks 4 --steps 2 --warmup 1 > "$out/rehearsal_2_ranks_config3_strong.json" 2>> "$out/rehearsal3.err"
 echo collected
