@@ -15,7 +15,7 @@ import glob
 import json
 import sys
 
-KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": "k2_rows_r16<false", "k3_cols_inv": "k3_cols_inv_",
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16<false", "k2_rows_h16"), "k3_cols_inv": "k3_cols_inv_",
         "tile_stats": "stats_reduce", "peaks": "peaks_kernel",
         "k2_rows_group": "k2_rows_r16_group"}   # (peaks_wide / peaks_finish return at once on this workload)
 
@@ -41,7 +41,7 @@ def main():
         def pick(vals):
             best = []
             for name, lst in vals.items():
-                if pat in name:
+                if any(p_ in name for p_ in ((pat,) if isinstance(pat, str) else pat)):
                     gmax = max(g for _, g in lst)          # full-size launches only (skip the 1-pair needle launch)
                     best += [v for v, g in lst if g == gmax]
             # median over the full-size launches: the first call with a needle writes every raw
