@@ -66,6 +66,39 @@ extern "C" {
         pool: *mut AmPool, haystacks: *const *const f32, lens: *const usize, n_hay: usize,
         p: *const AmMatchParams, out: *mut AmPeak, cap_per_hay: usize, n_out: *mut usize,
     ) -> c_int;
+    /// the same loop on the decoder's interleaved i16 stereo frames (mp3_reader.rs:26-37)
+    pub fn am_pool_match_batch_pcm16(
+        pool: *mut AmPool, interleaved: *const *const i16, frames: *const usize, n_hay: usize,
+        p: *const AmMatchParams, out: *mut AmPeak, cap_per_hay: usize, n_out: *mut usize,
+    ) -> c_int;
+    /// several snippets of one length: the haystack's forward transform is shared by a group of needles
+    pub fn am_match_multi_batch_device(
+        needles: *const *const AmNeedle, n_needles: usize, d_haystacks: *const *const std::ffi::c_void,
+        lens: *const usize, n_hay: usize, sample_format: c_int, p: *const AmMatchParams,
+        out: *mut AmPeak, cap_per_pair: usize, n_out: *mut usize,
+    ) -> c_int;
+    pub fn am_pool_create_multi(
+        needles: *const *const f32, n_needles: usize, n: usize, devices: *const c_int, n_dev: usize, out: *mut *mut AmPool,
+    ) -> c_int;
+    pub fn am_pool_match_multi_batch(
+        pool: *mut AmPool, haystacks: *const *const std::ffi::c_void, lens: *const usize, n_hay: usize, sample_format: c_int,
+        p: *const AmMatchParams, out: *mut AmPeak, cap_per_pair: usize, n_out: *mut usize,
+    ) -> c_int;
+    /// calc_chunks on the lazy sample iterator (audio_matcher.rs:88-104, mp3_reader.rs:13-41)
+    pub fn am_match_stream_begin(
+        h: *const AmNeedle, sample_format: c_int, expected_len: usize, p: *const AmMatchParams, out: *mut *mut AmStream,
+    ) -> c_int;
+    pub fn am_match_stream_push(st: *mut AmStream, samples: *const std::ffi::c_void, n: usize) -> c_int;
+    pub fn am_match_stream_finish(st: *mut AmStream, out: *mut AmPeak, cap: usize, n_out: *mut usize) -> c_int;
+    pub fn am_match_stream_destroy(st: *mut AmStream);
+}
+
+pub const AM_FMT_F32_MONO: c_int = 0;
+pub const AM_FMT_S16_STEREO: c_int = 1;
+
+#[repr(C)]
+pub struct AmStream {
+    _private: [u8; 0],
 }
 
 #[repr(C)]
@@ -243,5 +276,36 @@ impl HipConvolvePool {
 impl Drop for HipConvolvePool {
     fn drop(&mut self) {
         unsafe { am_pool_destroy(self.p) }
+    }
+}
+
+impl HipConvolve {
+    /// `calc_chunks` on the reference's own argument shape: a lazy `ExactSizeIterator` of samples
+    /// (audio_matcher.rs:88-97).  Blocks of samples are pushed as the iterator yields them; the
+    /// transforms of every block pair that has arrived run while the decoder is still producing.
+    pub fn calc_chunks_iter<I: ExactSizeIterator<Item = f32>>(&self, p: &AmMatchParams, m_samples: I)
+        -> Result<Vec<AmPeak>, Box<dyn std::error::Error>> {
+        let mut st = std::ptr::null_mut();
+        let rc = unsafe { am_match_stream_begin(self.h, AM_FMT_F32_MONO, m_samples.len(), p, &mut st) };
+        if rc != AM_OK { return Err(am_err(rc)); }
+        let mut block: Vec<f32> = Vec::with_capacity(1 << 20);
+        let mut push = |b: &mut Vec<f32>| -> c_int {
+            let rc = unsafe { am_match_stream_push(st, b.as_ptr().cast(), b.len()) };
+            b.clear();
+            rc
+        };
+        let mut rc = AM_OK;
+        for x in m_samples {
+            block.push(x);
+            if block.len() == block.capacity() { rc = push(&mut block); if rc != AM_OK { break; } }
+        }
+        if rc == AM_OK { rc = push(&mut block); }
+        let mut buf = vec![AmPeak::default(); 256];
+        let mut n = 0usize;
+        if rc == AM_OK { rc = unsafe { am_match_stream_finish(st, buf.as_mut_ptr(), buf.len(), &mut n) }; }
+        unsafe { am_match_stream_destroy(st) };
+        if rc != AM_OK { return Err(am_err(rc)); }
+        buf.truncate(n);
+        Ok(buf)
     }
 }
