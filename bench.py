@@ -128,13 +128,16 @@ class Workload:
     def kernel_bytes(self, dense=False):
         g = self.geo
         pts = g["npairs"] * g["n_fft"]
+        # one point of the work matrix: a float2, or a half2 with --half-pipeline 1 / 2
+        pt = 4 if self.am.get_option("half_pipeline") else 8
+        spec = 4 if self.am.get_option("half_pipeline") >= 2 else 8   # (level 2 multiplies with an f16 copy of the spectrum)
         return {
-            "k1_cols_fwd": pts * (8 + 8),                      # two f32 blocks in, one complex point out
-            # complex in, complex out; the needle spectrum (8 B per point of ONE transform) is shared by all
+            "k1_cols_fwd": pts * (8 + pt),                     # two f32 blocks in, one complex point out
+            # complex in, complex out; the needle spectrum (one transform's worth) is shared by all
             # pairs through L2 and has to come from HBM once per launch, not once per pair
-            "k2_rows": pts * (8 + 8) + g["n_fft"] * 8,
+            "k2_rows": pts * (pt + pt) + g["n_fft"] * spec,
             # complex in, (min,max) per 32 scores out; raw scores only where the pick can need them
-            "k3_cols_inv": pts * 8 + (g["out_count"] // 32) * 8 + (g["out_count"] * 4 if dense else 0),
+            "k3_cols_inv": pts * pt + (g["out_count"] // 32) * 8 + (g["out_count"] * 4 if dense else 0),
         }
 
     def dominant_bytes_per_launch(self):
@@ -787,7 +790,7 @@ def make_tonal(am, device, s, h):
     needle = rng.uniform(-0.25, 0.25, s).astype(np.float32) + tone[:s] + np.float32(0.1)
     hay = rng.uniform(-0.25, 0.25, h).astype(np.float32) + tone + drift
     del tone, drift
-    plants = plant_offsets(0)
+    plants = [t for t in plant_offsets(0) if t + s <= h]
     for p0 in plants:
         hay[p0:p0 + s] += needle
     return (*_upload(am, device, needle, hay, s), plants,
@@ -813,7 +816,7 @@ def make_ar1(am, device, s, h):
     rng = np.random.default_rng(7)
     needle = _ar1(rng, s, 0.95, 0.5)
     hay = _ar1(rng, h, 0.95, 0.5)
-    plants = plant_offsets(0)
+    plants = [t for t in plant_offsets(0) if t + s <= h]
     for p0 in plants:
         hay[p0:p0 + s] += needle
     return (*_upload(am, device, needle, hay, s), plants,
@@ -832,7 +835,7 @@ def make_speechlike(am, device, s, h):
     needle = _ar1(rng, s, 0.9, 0.5)
     hay = _ar1(rng, h, 0.9, 0.6) * env.astype(np.float32)
     del env
-    plants = plant_offsets(0)
+    plants = [t for t in plant_offsets(0) if t + s <= h]
     for p0 in plants:
         hay[p0:p0 + s] += needle
     return (*_upload(am, device, needle, hay, s), plants,

@@ -521,3 +521,31 @@ def test_half_pipeline_overflow_falls_back_to_f32(gpu, oracle):
     for r in (res[0], res[2]):                                # stayed in half precision: offsets, heights to 2e-3
         assert pos(r) == pos(want_calm)
         assert all(abs(g.height - o.height) < 2e-3 for g, o in zip(r, want_calm)) and key(r) != key(want_calm)
+
+
+# ---------------------------------------------------------------------------
+# the non-white signals of bench.py against the checker
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["non_white_signal", "non_white_ar1", "non_white_speechlike"])
+def test_non_white_generators_against_the_checker(gpu, oracle, name):
+    """bench.py's three non-white signals (tone and drift, AR(1) noise, AR(1) under a speech-like
+    envelope) at 20 minutes of 44.1 kHz audio with the 10 s needle: offsets, plateau ends, heights and
+    prominences of am_match_device equal the checker's (audio_matcher.rs:88-141), as a single call and
+    inside a batch."""
+    import bench
+    sr = 44100
+    s, h = 10 * sr, 1200 * sr
+    nbuf, algo, hbuf, plants, _ = bench.NON_WHITE[name](gpu, 0, s, h)
+    assert len(plants) == 2
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=480.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    needle, hay = nbuf.to_numpy("float32", s), hbuf.to_numpy("float32", h)
+    exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.13, p.min_distance, 480.0)
+    assert [e[0] for e in exp] == plants
+    got = algo.match_device(hbuf.ptr, h, p)
+    assert_same(got, exp)
+    res = algo.match_batch_device([hbuf.ptr] * 3, [h] * 3, p)
+    assert [key(r) for r in res] == [key(got)] * 3
+    # a smaller prominence bound and no distance filter: many peaks per chunk, still the checker's
+    p2 = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=0.0, prominence=0.02).params(sr, gpu.Scale.LIB)
+    exp2 = oracle.calc_chunks(sr, hay, needle, p2.chunk, p2.overlap, 0.02, p2.min_distance, 0.0)
+    assert_same(algo.match_device(hbuf.ptr, h, p2, cap=1 << 20), exp2)
