@@ -547,5 +547,6 @@ def test_non_white_generators_against_the_checker(gpu, oracle, name):
     assert [key(r) for r in res] == [key(got)] * 3
     # a smaller prominence bound and no distance filter: many peaks per chunk, still the checker's
     p2 = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=0.0, prominence=0.02).params(sr, gpu.Scale.LIB)
-    exp2 = oracle.calc_chunks(sr, hay, needle, p2.chunk, p2.overlap, 0.02, p2.min_distance, 0.0)
+    exp2 = oracle.calc_chunks(sr, hay, needle, p2.chunk, p2.overlap, 0.02, p2.min_distance, 0.0, cap=1 << 20)
+    assert len(exp2) < (1 << 20)
     assert_same(algo.match_device(hbuf.ptr, h, p2, cap=1 << 20), exp2)
