@@ -157,9 +157,10 @@ def test_pcm_downmix_bit_exact(gpu, oracle):
 
 
 def test_sparse_score_path_after_first_call(gpu, oracle):
-    """The first call with a needle writes every raw score; later calls write
-    raw scores only for tiles with a score >= theta (fused scan).  Both paths
-    must give the oracle's answer, also at the production transform size."""
+    """Raw scores are written only for the 32-score runs whose maximum reaches their K3 tile's
+    write threshold (tile minimum, bounded by the needle's recent chunk minima, plus half a
+    prominence); the threshold's history changes from call to call.  Every call must give the
+    oracle's answer, also at the production transform size."""
     sr = 44100
     needle, hay = synth_case(oracle, sr, 10.0, 150.0, [20.0, 95.5, 130.0])
     cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=30.0, prominence=0.13)
@@ -175,9 +176,9 @@ def test_sparse_score_path_after_first_call(gpu, oracle):
 
 
 def test_theta_certificate_failure_falls_back(gpu, oracle):
-    """A quiet haystack first (high theta learned), then a loud one whose chunk
-    minimum is far lower: the certificate fails and the haystack is redone with
-    every score written; the answer still equals the oracle's."""
+    """A quiet haystack first, then a loud one whose chunk minima are far lower, then quiet again:
+    the write threshold follows the tile's own minimum (no certificate failure on the way down) and
+    the recent-minimum ring (on the way up); the answer equals the oracle's throughout."""
     sr = 44100
     s = 5 * sr
     needle = oracle.synth_uniform(2, 0, 0, s)

@@ -272,8 +272,8 @@ def test_dense_scores_option_is_result_neutral(gpu, oracle):
     cfg = gpu.Config(chunk_size_s=60.0, overlap_length_s=4.0, distance_s=30.0, prominence=0.13)
     p = cfg.params(sr, gpu.Scale.LIB)
     algo = gpu.HipConvolve(needle)
-    first = key(algo.match(hay, p))            # no history: dense
-    sparse = key(algo.match(hay, p))           # sparse
+    first = key(algo.match(hay, p))            # sparse, no history yet
+    sparse = key(algo.match(hay, p))           # sparse, threshold bounded by the first call's minima
     gpu.set_option("dense_scores", 1)
     try:
         dense = key(algo.match(hay, p))
@@ -283,10 +283,10 @@ def test_dense_scores_option_is_result_neutral(gpu, oracle):
 
 
 def test_failed_certificate_redoes_only_that_chunk(gpu, oracle):
-    """The raw-score threshold adapts to the lowest chunk minimum seen with a needle.  A later
-    haystack with one chunk whose minimum lies far below it (an inverted copy of the needle:
-    score -1) fails that chunk's certificate; the chunk is redone in place and the result
-    equals both the oracle and a fresh handle's (dense) answer bit for bit."""
+    """A chunk whose minimum lies far below what the K3 tiles sampled (an inverted copy of the
+    needle: a dip to -1 a few scores wide, missed by all but one of the 256 tiles) fails its
+    certificate; the chunk is redone in place with every run written and the result equals the
+    oracle and a fresh handle's answer bit for bit, also inside a batch."""
     sr = 44100
     s = 3 * sr
     needle = oracle.synth_uniform(15, 0, 0, s)
@@ -302,7 +302,7 @@ def test_failed_certificate_redoes_only_that_chunk(gpu, oracle):
     assert [e[0] for e in exp] == [75 * sr, 150 * sr]
     fresh = key(gpu.HipConvolve(needle).match(wild, p))
     algo = gpu.HipConvolve(needle)
-    algo.match(calm, p)                                      # history: minimum ~ -0.03
+    algo.match(calm, p)                                      # recent minimum ~ -0.03
     got = algo.match(wild, p)                                # chunk 1 fails its certificate
     assert key(got) == fresh
     assert_same(got, exp)
