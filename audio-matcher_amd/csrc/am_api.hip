@@ -250,9 +250,9 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     Plan p;
     int logN1 = logN - 13;
     if (logN1 < kColsLog) logN1 = kColsLog;
-    if (logN1 > 9) logN1 = 9;
+    if (logN1 > 10) logN1 = 10;
     int logN2 = logN - logN1;
-    // N = 2^21 -> 256 x 8192 and N = 2^22 -> 512 x 8192: the register kernels
+    // N = 2^21 -> 256 x 8192, N = 2^22 -> 512 x 8192, N = 2^23 -> 1024 x 8192: the register kernels
     const int logLo = (logN + 1) / 2;
     const size_t n1h = (size_t)1 << (logN1 - 1), n2h = (size_t)1 << (logN2 - 1);
     const size_t nlo = (size_t)1 << logLo, nhi = (size_t)1 << (logN - logLo);

@@ -66,7 +66,7 @@ def test_multi_block_overlap_save(gpu, oracle):
     assert np.abs(got - expect).max() < TOL
 
 
-@pytest.mark.parametrize("log_n", [10, 13, 17, 20, 22])
+@pytest.mark.parametrize("log_n", [10, 13, 17, 20, 22, 23])
 def test_every_plan_shape(gpu, oracle, log_n):
     """Each transform factorisation N1 x N2 against the oracle."""
     rng = np.random.default_rng(log_n)

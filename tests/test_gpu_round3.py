@@ -550,3 +550,44 @@ def test_non_white_generators_against_the_checker(gpu, oracle, name):
     exp2 = oracle.calc_chunks(sr, hay, needle, p2.chunk, p2.overlap, 0.02, p2.min_distance, 0.0, cap=1 << 20)
     assert len(exp2) < (1 << 20)
     assert_same(algo.match_device(hbuf.ptr, h, p2, cap=1 << 20), exp2)
+
+
+# ---------------------------------------------------------------------------
+# N = 2^23 = 1024 x 8192
+# ---------------------------------------------------------------------------
+def test_plan_2_23_correlate_and_match(gpu, oracle):
+    """The 1024-row column kernels (N = 2^23): several blocks and pairs with an odd block count through
+    level 1 against the checker, and calc_chunks (fused score scan of the 1024-row K3, sparse raw scores,
+    i16 ingest) against the checker and against the default plan's offsets."""
+    rng = np.random.default_rng(23)
+    needle = rng.uniform(-1, 1, 100000).astype(np.float32)
+    within = rng.uniform(-1, 1, 20_000_000).astype(np.float32)
+    algo = gpu.HipConvolve(needle)
+    algo.set_option("log_n", 23)
+    got = algo.correlate_with_sample(within, gpu.Mode.Valid, True)
+    expect = oracle.correlate(within, needle, oracle.MODE_VALID, oracle.SCALE_LIB, oracle.FFT_POW2)
+    assert got.shape == expect.shape and float(np.abs(got - expect).max()) < TOL
+    del got, expect, within
+    sr = 8000
+    s = 5 * sr
+    nd = oracle.synth_uniform(23, 0, 0, s)
+    hay = oracle.synth_uniform(23, 1, 0, 2700 * sr)             # 21.6 M samples: three blocks of 2^23
+    plants = [17.0, 1043.5, 1044.75, 2099.0, 2690.0]
+    for t in plants:
+        off = int(t * sr)
+        hay[off:off + s] += nd
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=5.0, distance_s=30.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    exp = oracle.calc_chunks(sr, hay, nd, p.chunk, p.overlap, 0.13, p.min_distance, 30.0)
+    wide = gpu.HipConvolve(nd)
+    wide.set_option("log_n", 23)
+    for _ in range(2):
+        assert_same(wide.match(hay, p), exp)
+    assert pos(gpu.HipConvolve(nd).match(hay, p)) == pos(wide.match(hay, p))
+    bufs = [gpu.DeviceBuffer.from_numpy(0, hay) for _ in range(2)]
+    res = wide.match_batch_device([b.ptr for b in bufs], [hay.size] * 2, p)
+    assert key(res[0]) == key(res[1]) == key(wide.match(hay, p))
+    gpu.set_option("dense_scores", 1)
+    try:
+        assert key(wide.match(hay, p)) == key(res[0])
+    finally:
+        gpu.set_option("dense_scores", 0)
