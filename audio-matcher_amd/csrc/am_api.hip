@@ -79,12 +79,15 @@ static const int kLogNMin = 10, kLogNMax = 23;
 // needles longer than this run on N = 2^22 (measured crossover between 4 and 7 s of 44.1 kHz
 // audio, tools/needle_sweep.py, profiles/r02/needle_sweep.txt)
 static const long long kWideFromSamples = 300000;
-// Needles longer than this (the longest the 2^22 plan takes) are cut into segments of at most 2^21 samples:
-// corr(hay, needle)[j] = sum_i corr(hay, segment_i)[j + offset_i], every segment on the register kernels,
-// the partial sums added up in the score array by K3 (MyConvolve::correlate accepts any length,
-// audio_matcher.rs:414-457).
-static const long long kSegmentFrom = (1ll << 22) - (1ll << 20);
-static const long long kSegmentLen = 1ll << 21;
+// needles longer than this run on N = 2^23 = 1024 x 8192 (measured crossover between 30 and 40 s of 44.1 kHz
+// audio, profiles/r03/needle_sweep.txt: the 1024-row column kernels cost more per point, the hop is longer)
+static const long long kWidestFromSamples = 1600000;
+// Needles longer than this (half a 2^23 transform) are cut into segments of at most 2^22 samples:
+// corr(hay, needle)[j] = sum_i corr(hay, segment_i)[j + offset_i], every segment on the register kernels
+// of the 2^23 plan (hop efficiency of at least one half), the partial sums added up in the score array by
+// K3 (MyConvolve::correlate accepts any length, audio_matcher.rs:414-457).
+static const long long kSegmentFrom = 1ll << 22;
+static const long long kSegmentLen = 1ll << 22;
 
 // ---------------------------------------------------------------------------
 struct DevBuf {
@@ -341,12 +344,19 @@ static int pick_log_n(size_t s, long long out_count, const Opts& o, int* logN_ou
     if (span > (1ll << 19)) {
         // measured crossover (tools/needle_sweep.py)
         if ((long long)s <= kWideFromSamples) { *logN_out = 21; return AM_OK; }
-        if ((long long)s <= (1ll << 22) - (1ll << 20)) {
+        if ((long long)s <= kWidestFromSamples) {
             // a short haystack (BASELINE configs[0]: one 60 s window) whose scores fit ONE pair of 2^21
             // blocks does not pay for a pair of 2^22 (half the points, same number of launches)
             long long hop21 = (1ll << 21) - (long long)s + 1;
             if (hop21 >= 8 * kTile) hop21 = (hop21 / kTile) * kTile;
             *logN_out = (hop21 > 0 && out_count <= 2 * hop21) ? 21 : 22;
+            return AM_OK;
+        }
+        if ((long long)s <= kSegmentFrom) {
+            // long needles: 2^23, unless the scores fit one pair of 2^22 blocks
+            long long hop22 = (1ll << 22) - (long long)s + 1;
+            if (hop22 >= 8 * kTile) hop22 = (hop22 / kTile) * kTile;
+            *logN_out = (hop22 > 0 && out_count <= 2 * hop22) ? 22 : 23;
             return AM_OK;
         }
     }
@@ -1492,7 +1502,7 @@ static int stream_layout(am_stream* st) {
     st->pairs_done = 0;
     if (st->cap < h->n || st->p.scale == AM_SCALE_MY || st->p.chunk == 0) return AM_OK;
     if (h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0) return AM_OK;               // direct summation: no blocks
-    if (o.log_n == 0 && (long long)h->n > (1ll << 22) - (1ll << 20)) return AM_OK;    // the plan depends on the final length
+    if (o.log_n == 0 && (long long)h->n > kWidestFromSamples) return AM_OK;    // the plan depends on the final length / the needle is partitioned
     const long long out_cap = (long long)(st->cap - h->n + 1);
     int rc = plan_geometry(h->n, out_cap, o, &st->geo);
     if (rc) return rc;

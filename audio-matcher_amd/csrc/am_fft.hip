@@ -1690,8 +1690,10 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
 //   W_64^(b*b') = W_4^(m*q) * W_64^(b0*q) * W_16^(b0*beta),
 // so thread (a', q) reads all 64 values of its a', forms y[b0] = (sum_m x[b0 + 16 m] (-i)^(m q)) W_64^(b0 q)
 // and transforms y over b0.  q = t >> 8 is uniform over a wavefront: the four cases do not diverge.
-// A 10 s needle needs 20 blocks of this size per hour of 44.1 kHz audio against 43 of 2^22: 9 % fewer
-// points; a 30 s needle 19 % fewer.
+// With one workgroup per CU every wave of a CU is in the same phase of its tile (two 512-thread workgroups
+// drift apart and overlap one's loads with the other's arithmetic): per point K1 costs 1.33x and K3 1.8x
+// their 512-row forms (profiles/r03/needle_sweep.txt), so the plan pays from about 36 s of 44.1 kHz needle
+// up, where the longer hop outweighs that (60 s: 1.26 ms per hour of audio against 1.74).
 // ===========================================================================
 constexpr int kC1024Slab = 64 * 17 + 16;   // float2 per a' slab: 64 rows of 17 + 16 (consecutive a' 32 banks apart)
 __device__ __forceinline__ int c1024_idx(int ap, int b, int cp) { return ap * kC1024Slab + b * 17 + cp; }
@@ -1801,6 +1803,7 @@ k1_cols_fwd_c1024(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
+template <bool ACC>   // ACC: add to what job.dst holds (needle partitioning, see k3_finish)
 __global__ void __launch_bounds__(1024)
 k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1867,7 +1870,7 @@ k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float ou
     twiddle_nat<16, true>(x1, w1024);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*64 + b
     dif<16, true>(x1);
-    k3_finish<6, float2, false>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_finish<6, float2, ACC>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -2128,7 +2131,8 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k1_cols_fwd_c512<1, 2>), kC512Lds)
     AM_SET_LDS(k1_cols_fwd_c1024<0>, kC1024Lds)
     AM_SET_LDS(k1_cols_fwd_c1024<1>, kC1024Lds)
-    AM_SET_LDS(k3_cols_inv_c1024, kC1024Lds)
+    AM_SET_LDS(k3_cols_inv_c1024<false>, kC1024Lds)
+    AM_SET_LDS(k3_cols_inv_c1024<true>, kC1024Lds)
     AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
     AM_SET_LDS((k3_cols_inv_c512<0, true>), kC512Lds)
     AM_SET_LDS((k3_cols_inv_r16<0, true>), kR16LdsK3)
@@ -2229,9 +2233,11 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (accumulate && half) return hipErrorInvalidValue;   // (the accumulating forms exist for the f32 work matrix only)
     if (plan_is_c1024(pl)) {
-        if (accumulate || half) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k3_cols_inv_c1024, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(1024), kC1024Lds, st, job, work,
-                           pl, out_scale, scan);
+        if (half) return hipErrorInvalidValue;
+        if (accumulate) hipLaunchKernelGGL(k3_cols_inv_c1024<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(1024), kC1024Lds, st, job, work,
+                                           pl, out_scale, scan);
+        else hipLaunchKernelGGL(k3_cols_inv_c1024<false>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(1024), kC1024Lds, st, job, work,
+                                pl, out_scale, scan);
     } else if (accumulate && plan_is_c512(pl)) {
         hipLaunchKernelGGL((k3_cols_inv_c512<0, true>), dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(512), kC512Lds, st, job, work,
                            pl, out_scale, scan);
