@@ -526,8 +526,8 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
                                ScanRequest* scan_req, int src_kind, bool accumulate);
 
 // The overlap-save engine for any needle length: one pass, or one pass per needle segment with the
-// source shifted by the segment's offset and K3 adding up the partial sums (the last pass carries
-// the fused scan, over the sums; every run is written).
+// source shifted by the segment's offset and K3 adding up the partial sums (plain scores, every one
+// written; the peak pick summarises them with tile_stats instead of the fused scan).
 static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long long src_len, long long lead,
                            float* d_dst, long long out_count, float factor,
                            ScanRequest* scan_req = nullptr, int src_kind = 0) {
@@ -539,12 +539,12 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
     os.half = 0;   // (the accumulating K3 exists for the f32 work matrix)
     const size_t nseg = h->segments.size();
     for (size_t i = 0; i < nseg; ++i) {
-        ScanRequest* sr = nullptr;
+        // every pass writes (i = 0) or adds (i > 0) plain scores; a pass still honours the restriction to the
+        // blocks of one chunk, and the first one may not touch the score buffer before the pick that last
+        // read it is done
         ScanRequest plain{};
-        if (i + 1 == nseg && scan_req) { scan_req->margin = -1.0f; sr = scan_req; }
-        else if (scan_req) {
-            // a pass without the scan still honours the restriction to the blocks of one chunk, and the
-            // first one may not touch the score buffer before the pick that last read it is done
+        ScanRequest* sr = nullptr;
+        if (scan_req) {
             plain.margin = -1.0f; plain.range_a = scan_req->range_a; plain.range_b = scan_req->range_b;
             plain.before_k3 = i == 0 ? scan_req->before_k3 : nullptr;
             plain.no_scan = true;
@@ -552,6 +552,10 @@ static int run_correlation(am_needle* h, const Opts& o, const void* d_src, long 
         }
         if ((rc = run_correlation_one(h->segments[i], os, d_src, src_len, lead - h->seg_off[i], d_dst, out_count, factor, sr, src_kind, i > 0)))
             return rc;
+    }
+    if (scan_req) {   // the sums are complete scores without a level-0 summary: the pick summarises them itself (tile_stats)
+        scan_req->fused = false;
+        scan_req->sparse = SparseScores{nullptr, nullptr, nullptr, 1, 5, 5, 1.0};
     }
     return AM_OK;
 }

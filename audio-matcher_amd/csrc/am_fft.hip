@@ -1112,7 +1112,9 @@ __device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan,
 // n1 = a * 2^HB + hi (columns col, col+1; real part = block A, imaginary part = block B):
 // scaling, fused score scan, block vote, conditional raw-score store.
 // ACC: the scores are added to what job.dst already holds (needle partitioning: the correlation with a long
-// needle is the sum of the correlations with its segments, each on a shifted source; every run is written).
+// needle is the sum of the correlations with its segments, each on a shifted source).  Every score is written
+// and the fused scan is left out -- scan and accumulation together do not fit the 128 registers of the
+// 1024-thread kernel (over a thousand spilled values); the sums get their summary from tile_stats instead.
 template <int HB, typename T, bool ACC = false>
 __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, const K3Edges& ed, float2* lds2,
                                           int n2_0, int out_stride, int t, long long blkA, long long blkB,
@@ -1132,25 +1134,9 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
         sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
     }
-    if (ACC) {
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
-            if (dst8 && n + 1 < limA) { const float2 o = *reinterpret_cast<const float2*>(job.dst + outA + n); sa0[a] += o.x; sa1[a] += o.y; }
-            else {
-                if (n < limA) sa0[a] += job.dst[outA + n];
-                if (n + 1 < limA) sa1[a] += job.dst[outA + n + 1];
-            }
-            if (dst8 && n + 1 < limB) { const float2 o = *reinterpret_cast<const float2*>(job.dst + outB + n); sb0[a] += o.x; sb1[a] += o.y; }
-            else {
-                if (n < limB) sb0[a] += job.dst[outB + n];
-                if (n + 1 < limB) sb1[a] += job.dst[outB + n + 1];
-            }
-        }
-    }
     // which of this thread's 16 rows leave the chip as raw scores (bit a = row a * 2^HB + hi), per block
     unsigned wantA = 0xFFFFu, wantB = 0xFFFFu;
-    if (scan.stats32 != nullptr) {
+    if (!ACC && scan.stats32 != nullptr) {   // (the accumulating form writes plain scores: its sums are summarised by tile_stats)
         // ---- fused score scan: (min,max) per 32 consecutive scores ------------
         // this thread owns the run of row n1 = row (scores row*out_stride + n2_0 .. +31 of both blocks)
         const int row = scan_row_of<HB>(t);
@@ -1234,11 +1220,17 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
             const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
             // hop and out offsets are even whenever this kernel is used, so a pair is
             // valid or invalid as a whole except at the very end of the score array
-            if (dst8 && n + 1 < limA) *reinterpret_cast<float2*>(job.dst + outA + n) = make_float2(sa0[a], sa1[a]);
-            else {
-                if (n < limA) job.dst[outA + n] = sa0[a];
-                if (n + 1 < limA) job.dst[outA + n + 1] = sa1[a];
+            // (ACC: read-modify-write right here -- the sums are needed nowhere else, see above)
+            if (dst8 && n + 1 < limA) {
+                float2* ptr = reinterpret_cast<float2*>(job.dst + outA + n);
+                float2 v = make_float2(sa0[a], sa1[a]);
+                if (ACC) { const float2 o = *ptr; v.x += o.x; v.y += o.y; }
+                *ptr = v;
+            } else {
+                if (n < limA) job.dst[outA + n] = sa0[a] + (ACC ? job.dst[outA + n] : 0.0f);
+                if (n + 1 < limA) job.dst[outA + n + 1] = sa1[a] + (ACC ? job.dst[outA + n + 1] : 0.0f);
             }
+            if (ACC && (a & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the read-modify-writes from being hoisted all at once)
         }
     }
     if (wantB) {
@@ -1246,11 +1238,16 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         for (int a = 0; a < 16; ++a) {
             if (!((wantB >> a) & 1u)) continue;
             const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
-            if (dst8 && n + 1 < limB) *reinterpret_cast<float2*>(job.dst + outB + n) = make_float2(sb0[a], sb1[a]);
-            else {
-                if (n < limB) job.dst[outB + n] = sb0[a];
-                if (n + 1 < limB) job.dst[outB + n + 1] = sb1[a];
+            if (dst8 && n + 1 < limB) {
+                float2* ptr = reinterpret_cast<float2*>(job.dst + outB + n);
+                float2 v = make_float2(sb0[a], sb1[a]);
+                if (ACC) { const float2 o = *ptr; v.x += o.x; v.y += o.y; }
+                *ptr = v;
+            } else {
+                if (n < limB) job.dst[outB + n] = sb0[a] + (ACC ? job.dst[outB + n] : 0.0f);
+                if (n + 1 < limB) job.dst[outB + n + 1] = sb1[a] + (ACC ? job.dst[outB + n + 1] : 0.0f);
             }
+            if (ACC && (a & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -2232,6 +2229,7 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, int half, bool accumulate) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     if (accumulate && half) return hipErrorInvalidValue;   // (the accumulating forms exist for the f32 work matrix only)
+    if (accumulate && (plan_has_scan(pl)) && ((reinterpret_cast<uintptr_t>(job.dst) & 7) != 0 || (job.hop & 1) != 0)) return hipErrorInvalidValue;
     if (plan_is_c1024(pl)) {
         if (half) return hipErrorInvalidValue;
         if (accumulate) hipLaunchKernelGGL(k3_cols_inv_c1024<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(1024), kC1024Lds, st, job, work,
