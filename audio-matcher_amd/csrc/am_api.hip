@@ -79,9 +79,9 @@ static const int kLogNMin = 10, kLogNMax = 23;
 // needles longer than this run on N = 2^22 (measured crossover between 4 and 7 s of 44.1 kHz
 // audio, tools/needle_sweep.py, profiles/r02/needle_sweep.txt)
 static const long long kWideFromSamples = 300000;
-// needles longer than this run on N = 2^23 = 1024 x 8192 (measured crossover between 30 and 40 s of 44.1 kHz
+// needles longer than this run on N = 2^23 = 1024 x 8192 (measured crossover between 30 and 36 s of 44.1 kHz
 // audio, profiles/r03/needle_sweep.txt: the 1024-row column kernels cost more per point, the hop is longer)
-static const long long kWidestFromSamples = 1600000;
+static const long long kWidestFromSamples = 1500000;
 // Needles longer than this (half a 2^23 transform) are cut into segments of at most 2^22 samples:
 // corr(hay, needle)[j] = sum_i corr(hay, segment_i)[j + offset_i], every segment on the register kernels
 // of the 2^23 plan (hop efficiency of at least one half), the partial sums added up in the score array by
