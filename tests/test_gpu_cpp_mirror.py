@@ -1,4 +1,4 @@
-"""The C++ host mirror (include/audiomatch.hpp: CorrelateAlgo, HipConvolve, HipConvolvePool, Config, calc_chunks
+"""The C++ host mirror (include/audiomatch.hpp: CorrelateAlgo, HipConvolve, HipConvolvePool, HipConvolveMultiPool, Config, calc_chunks
 with the reference's names, audio_matcher.rs:65-141, matcher/mod.rs:42-87) driven from a real C++ program on the GPU."""
 import os
 import subprocess
@@ -43,6 +43,14 @@ int main(int argc, char** argv) {
     std::printf("pool %zu", pool.size());
     for (const auto& one : all) { std::printf(" |"); for (const Peak& p : one) std::printf(" %zu", p.start); }
     std::printf("\n");
+    // several snippets over the devices of the node: the second "snippet" is the first one delayed by 100 samples
+    std::vector<float> shifted(needle.size(), 0.0f);
+    for (size_t i = 100; i < needle.size(); ++i) shifted[i] = needle[i - 100];
+    HipConvolveMultiPool multi({needle, shifted}, {0, 0});
+    const auto pairs = multi.calc_chunks(8000, {hay.data(), half.data()}, {hay.size(), half.size()}, AM_FMT_F32_MONO, true, cfg);
+    std::printf("multi");
+    for (const auto& per_hay : pairs) for (const auto& one : per_hay) { std::printf(" |"); for (const Peak& p : one) std::printf(" %zu", p.start); }
+    std::printf("\n");
     algo.set_option("log_n", 16);
     std::printf("peaks16 %zu\n", calc_chunks(8000, hay.data(), hay.size(), algo, true, cfg).size());
     try { HipConvolve bad(std::vector<float>{}); } catch (const Error& e) { std::printf("error %d\n", e.code); }
@@ -82,5 +90,8 @@ def test_cpp_mirror_program(gpu, oracle, tmp_path):
         assert abs(float(p[2]) - e[2]) < 1e-4 and abs(float(p[3]) - e[3]) < 1e-4
     pool = [l for l in out if l.startswith("pool")][0]
     assert pool == f"pool 2 | {4 * sr} {17 * sr} | {4 * sr} | {4 * sr} {17 * sr}"
+    # needle 2 = needle 1 delayed by 100 samples (its first 100 samples zero): its hits lie 100 samples earlier
+    multi = [l for l in out if l.startswith("multi")][0]
+    assert multi == f"multi | {4 * sr} {17 * sr} | {4 * sr - 100} {17 * sr - 100} | {4 * sr} | {4 * sr - 100}"
     assert [l for l in out if l.startswith("peaks16")] == ["peaks16 2"]
     assert out[-1] == "error 1"          # AM_ERR_INVALID_ARG surfaces as audiomatch::Error

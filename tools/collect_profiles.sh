@@ -32,4 +32,7 @@ for cfg in 2 3 4; do
   python3 bench.py --gpus 2 --config $cfg $lean --steps 3 --warmup 1 --ramp-steps 2 --haystacks-per-step 2 > "$out/rehearsal_2_ranks_config$cfg.json" 2> "$out/rehearsal$cfg.err"
 done
 python3 bench.py --gpus 2 --config 3 $lean --total-haystacks 4 --steps 2 --warmup 1 > "$out/rehearsal_2_ranks_config3_strong.json" 2>> "$out/rehearsal3.err"
+# BASELINE configs[3] and [4] at their stated batch (1000 haystacks) on this one GPU, strong-scaling form, one pass
+python3 bench.py --config 3 $lean --total-haystacks 1000 --steps 1 --warmup 0 > "$out/strong_1000_config3_1_gpu.json" 2> "$out/strong3.err"
+python3 bench.py --config 4 $lean --total-haystacks 1000 --steps 1 --warmup 0 > "$out/strong_1000_config4_1_gpu.json" 2> "$out/strong4.err"
 echo collected
