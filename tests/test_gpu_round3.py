@@ -369,6 +369,14 @@ def test_stream_ingest_equals_am_match(gpu, oracle):
         total = prof.query("k1_cols_fwd")[1]
         st.close()
     assert key(res) == want[id(long_hay)] and after_push >= 1 and total > after_push
+    # a NaN that arrives in the middle of a stream whose early pairs are already transformed
+    bad = long_hay.copy()
+    bad[5000000] = np.nan
+    st = gpu.MatchStream(algo, p, bad.size)
+    push_ragged(st, bad, [3000000])
+    got_bad = key(st.finish())
+    st.close()
+    assert got_bad == key(algo.match(bad, p)) and len(got_bad) < len(want[id(long_hay)])
     # a forced generic plan (no early pairs) and MyConvolve scaling go through finish alone
     forced = gpu.HipConvolve(needle)
     forced.set_option("log_n", 17)
