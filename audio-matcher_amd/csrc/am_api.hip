@@ -144,6 +144,10 @@ struct Ctx {
     // second set of the score-side buffers: in a batch the peak pick of haystack k runs on
     // stream2 beside the transforms of haystack k+1, which then need their own set
     DevBuf scores_b, stats_b, stats32_b, wflags_b, peaks_b;
+    // device-side redo (batches): a second work matrix, so that the inverse rows of haystack k are still there
+    // when its pick has found chunks whose certificate failed, and the per-pair "run again" flags of both sets
+    DevBuf work_b, redo_pairs[2];
+    HostBuf failcnt;   // host-visible: one byte per chunk of a call, set when the chunk failed its certificate
     hipEvent_t ev_k3[2] = {nullptr, nullptr}, ev_pick[2] = {nullptr, nullptr};
     HostBuf pinned;
     // Per-chunk result headers live in coherent pinned host memory that the peak
@@ -182,6 +186,7 @@ static int get_ctx(int device, Ctx** out) {
     Ctx* c = new Ctx();
     c->device = device;
     c->hdr.flags = hipHostMallocMapped | hipHostMallocCoherent;
+    c->failcnt.flags = hipHostMallocMapped | hipHostMallocCoherent;
     c->spill.flags = hipHostMallocMapped | hipHostMallocCoherent;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
@@ -298,6 +303,11 @@ struct am_needle {
         recent_pos[sm] = (recent_pos[sm] + 1) % kRecent;
         if (recent_n[sm] < kRecent) ++recent_n[sm];
     }
+    // haystacks left for which the ring takes the LOWEST chunk minimum (after a haystack in which many chunks
+    // failed their certificate: a drifting score array); otherwise, where a failed chunk is redone on the
+    // device, it takes the median -- the background level -- so that a few chunks with deep dips (a hit whose
+    // autocorrelation has negative lobes) do not make every later haystack write all its scores
+    int conservative_left[2] = {0, 0};
     float hist_min(int sm) const {
         float m = FLT_MAX;
         for (int i = 0; i < recent_n[sm]; ++i) m = std::min(m, recent_min[sm][i]);
@@ -379,6 +389,7 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
     auto it = h->spectra.find(key);
     if (it != h->spectra.end()) { *out = it->second; return AM_OK; }
     const size_t N = (size_t)1 << pl->dev.logN;
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // (a device-side redo may still read the work matrix)
     int rc = c->work.ensure(std::max<size_t>(N * sizeof(float2), c->work.cap));
     if (rc) return rc;
     float2* hc = nullptr;
@@ -438,6 +449,10 @@ struct ScanRequest {
     DevBuf* ext_stats32; DevBuf* ext_side;
     bool skip_launch;
     bool no_scan;            // in: only the block restriction (range_a, range_b) applies; K3 writes plain scores
+    bool work_by_set;        // in: the work matrix of set 1 is the context's second one (kept for a device-side redo)
+    // out: what a second K3 launch over the same work matrix needs (valid when redo_ok)
+    bool redo_ok;
+    Job redo_job; PlanDev redo_pl; float redo_scale; int redo_half; int redo_npairs; const float2* redo_work; ScanCfg redo_cfg;
     bool fused;              // out: K3 produced stats32 / wflags
     SparseScores sparse;     // out: description of what was written
 };
@@ -587,7 +602,9 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
     const long long N = g.N, hop = g.hop, nblocks = g.nblocks, npairs = g.npairs;
     long long ppg = std::max<long long>(1, o.pairs_per_group);
     if (ppg > npairs) ppg = npairs;
-    if ((rc = c->work.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
+    DevBuf& wk = (scan_req && scan_req->work_by_set && scan_req->set) ? c->work_b : c->work;
+    if ((rc = wk.ensure((size_t)ppg * (size_t)N * sizeof(float2)))) return rc;
+    if (scan_req) scan_req->redo_ok = false;
     ScanCfg scan{};
     if (scan_req && !scan_req->no_scan) {
         scan_req->fused = false;
@@ -620,11 +637,18 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
     for (long long first = pair_lo; first < pair_hi; first += ppg) {
         const int np = (int)std::min(ppg, pair_hi - first);
         job.first_pair = (int)first;
-        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)c->work.p, pl->dev, hs.level)); }
-        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)c->work.p, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre)); }
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, np, (float2*)wk.p, pl->dev, hs.level)); }
+        { ProfScope ps(c, KN_K2); AM_HIP(launch_k2(c->stream, np, (float2*)wk.p, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre)); }
         if (!waited && scan_req && scan_req->before_k3) AM_HIP(hipStreamWaitEvent(c->stream, scan_req->before_k3, 0));
         waited = true;
-        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)c->work.p, pl->dev, k3scale, scan, hs.level, accumulate)); }
+        { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)wk.p, pl->dev, k3scale, scan, hs.level, accumulate)); }
+    }
+    if (scan_req && scan_req->fused && !accumulate && pair_lo == 0 && pair_hi == npairs && npairs <= ppg) {
+        // the whole haystack's inverse rows sit in one work matrix: K3 can run again over chosen pairs
+        scan_req->redo_ok = true;
+        job.first_pair = 0;
+        scan_req->redo_job = job; scan_req->redo_pl = pl->dev; scan_req->redo_scale = k3scale; scan_req->redo_half = hs.level;
+        scan_req->redo_npairs = (int)npairs; scan_req->redo_work = (const float2*)wk.p; scan_req->redo_cfg = scan;
     }
     return AM_OK;
 }
@@ -710,7 +734,7 @@ static int prepare_results(Ctx* c, size_t nhdr, size_t arena_entries, PeakArena*
 // context's segment buffer, result headers at [hdr_off, hdr_off + nsegs).
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
                        float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off,
-                       const PeakArena& arena, hipStream_t st = nullptr) {
+                       const PeakArena& arena, hipStream_t st = nullptr, bool only_failed = false) {
     if (!st) st = c->stream;
     const int set = scan ? scan->set : 0;
     DevBuf& bstats = set ? c->stats_b : c->stats;
@@ -721,7 +745,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
     int rc;
     const long long ntiles = (n_scores + kTile - 1) / kTile;
     if ((rc = bstats.ensure((size_t)ntiles * sizeof(float2)))) return rc;
-    {
+    if (!only_failed) {   // (a second pick after a device-side redo of K3 finds the summaries it left: the scores are the same)
         ProfScope ps(c, KN_STATS, st);
         int* bad = scan ? scan->bad : nullptr;
         if (d_stats32) AM_HIP(launch_stats_reduce(st, d_stats32, n_scores, (float2*)bstats.p, bad));
@@ -745,7 +769,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         ProfScope ps(c, KN_PEAKS, st);
         AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide));
+                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide, only_failed));
     }
     return AM_OK;
 }
@@ -1016,6 +1040,14 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     if ((rc = c->badflag.ensure(sizeof(int) * n_hay))) return rc;
     int* h_bad = static_cast<int*>(c->badflag.p);
     memset(h_bad, 0, sizeof(int) * n_hay);
+    if ((rc = c->failcnt.ensure(nsegs + 1))) return rc;
+    unsigned char* h_fail = static_cast<unsigned char*>(c->failcnt.p);
+    memset(h_fail, 0, nsegs + 1);
+    // A chunk whose certificate fails is redone on the device when the batch overlaps picks and transforms:
+    // the pick marks the block pairs that feed it, K3 runs once more for those pairs with every run written
+    // (from the haystack's own work matrix: two alternate) and the chunk is picked again -- all on the
+    // second stream, no host round trip.  (Single calls redo such a chunk from the host, below.)
+    const bool device_redo = overlap && sparse_ok && !needle_is_segmented(h, o);
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     auto chunk_events = [&](size_t k, int stage) {
         if (hooks.chunk_fn)
@@ -1033,7 +1065,18 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         const int set = overlap ? (int)(seq & 1) : 0;
         float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
         scan.set = set;
-        scan.before_k3 = (overlap && seq >= 2) ? c->ev_pick[set] : nullptr;
+        // this set's work matrix, scores and summaries are overwritten: the pick (and redo) that last used them must be done
+        if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
+        scan.before_k3 = nullptr;
+        scan.work_by_set = overlap;
+        int* d_redo = nullptr;
+        if (device_redo) {
+            Geometry g{};
+            if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
+            if ((rc = c->redo_pairs[set].ensure(sizeof(int) * (size_t)g.npairs))) return rc;
+            AM_HIP(hipMemsetAsync(c->redo_pairs[set].p, 0, sizeof(int) * (size_t)g.npairs, c->stream));
+            d_redo = static_cast<int*>(c->redo_pairs[set].p);
+        }
         // (i16 frames are always finite -- but a half-precision transform can overflow on them)
         scan.bad = ((src_kind == 0 || o.half) && std::isfinite(factor)) ? &h_bad[k] : nullptr;
         if (pre) {
@@ -1053,8 +1096,23 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
             AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
         }
+        if (scan.fused && scan.sparse.wbits) {
+            scan.sparse.fail_flags = h_fail + seg_off[k];
+            scan.sparse.redo_pairs = (device_redo && scan.redo_ok) ? d_redo : nullptr;
+        }
         if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence,
                               (long long)p->min_distance, &scan, seg_off[k], arena, overlap ? c->stream2 : c->stream))) return rc;
+        if (scan.fused && scan.sparse.redo_pairs) {
+            ScanCfg cfg = scan.redo_cfg;
+            cfg.margin = -1.0f;
+            cfg.only_pairs = d_redo;
+            { ProfScope ps(c, KN_K3, c->stream2);
+              AM_HIP(launch_k3(c->stream2, scan.redo_job, scan.redo_npairs, scan.redo_work, scan.redo_pl, scan.redo_scale, cfg, scan.redo_half)); }
+            ScanRequest again = scan;
+            again.sparse.redo_pairs = nullptr; again.sparse.fail_flags = nullptr; again.bad = nullptr;
+            if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
+                                  &again, seg_off[k], arena, c->stream2, true))) return rc;
+        }
         if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
         ++seq;
     }
@@ -1079,9 +1137,16 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         // result of this call has been collected (the pass reuses the call's result area).
         if (h_bad[k] && o.half) { retry_f32.push_back(k); continue; }
         if (!my && !h_bad[k] && s1 > s0) {   // (a haystack with non-finite scores teaches the threshold nothing)
-            float lowest = FLT_MAX;
-            for (int i = s0; i < s1; ++i) lowest = std::min(lowest, h_hdr[i].seg_min);
-            h->remember_min(sm, lowest);
+            std::vector<float> mins;
+            int failed = 0;
+            for (int i = s0; i < s1; ++i) { mins.push_back(h_hdr[i].seg_min); failed += h_fail[i] != 0; }
+            std::sort(mins.begin(), mins.end());
+            // many failed certificates: a score array that drifts (chunk minima in other block pairs than the tiles'
+            // scores) -- the lowest minimum for a good while; a few, redone on the device: the background level
+            if (failed * 8 > s1 - s0) h->conservative_left[sm] = 64;
+            const bool robust = device_redo && h->conservative_left[sm] == 0;
+            h->remember_min(sm, robust ? mins[mins.size() / 2] : mins.front());
+            if (h->conservative_left[sm] > 0) --h->conservative_left[sm];
         }
         all.clear();
         // Non-finite samples (NaN, +-inf; f32 sources only).  The reference transforms every window
@@ -2077,13 +2142,14 @@ int am_shutdown(void) {
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
-                          &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b,
+                          &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b, &c->work_b, &c->redo_pairs[0], &c->redo_pairs[1],
                           &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur, &c->wide_ctl, &c->wide_list, &c->wide_tiles})
             b->release();
         if (c->pinned.p) { (void)hipHostFree(c->pinned.p); c->pinned.p = nullptr; c->pinned.cap = 0; }
         if (c->hdr.p) { (void)hipHostFree(c->hdr.p); c->hdr.p = nullptr; c->hdr.cap = 0; }
         if (c->spill.p) { (void)hipHostFree(c->spill.p); c->spill.p = nullptr; c->spill.cap = 0; }
         if (c->badflag.p) { (void)hipHostFree(c->badflag.p); c->badflag.p = nullptr; c->badflag.cap = 0; }
+        if (c->failcnt.p) { (void)hipHostFree(c->failcnt.p); c->failcnt.p = nullptr; c->failcnt.cap = 0; }
         c->ranges.release(); c->range_flags.release(); c->big.release();
         c->segs_resident.clear();
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);

@@ -1355,6 +1355,7 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
     const int n2_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
+    if (scan.only_pairs != nullptr && scan.only_pairs[pair] == 0) return;   // device-side redo: flagged pairs only
     const long long blkA = 2ll * pair, blkB = blkA + 1;
     if constexpr (HALF == 2) {
         const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
@@ -1551,6 +1552,7 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const unsigned slot = seq >> 5, hf = (seq >> 4) & 1u, tl = seq & 15u;
     const int n2_0 = (int)(((hf * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
+    if (scan.only_pairs != nullptr && scan.only_pairs[pair] == 0) return;   // device-side redo: flagged pairs only
     const long long blkA = 2ll * pair, blkB = blkA + 1;
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);
@@ -1814,6 +1816,7 @@ k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float ou
     const unsigned slot = seq >> 5, hf = (seq >> 4) & 1u, tl = seq & 15u;
     const int n2_0 = (int)(((hf * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
+    if (scan.only_pairs != nullptr && scan.only_pairs[pair] == 0) return;   // device-side redo: flagged pairs only
     const long long blkA = 2ll * pair, blkB = blkA + 1;
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);

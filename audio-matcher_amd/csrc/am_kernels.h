@@ -77,6 +77,10 @@ struct ScanCfg {
     float hist_min;           // lowest chunk minimum of the needle's recent haystacks (FLT_MAX: none)
     long long seg_c, seg_d;   // chunk geometry: runs that hold score i*seg_c or i*seg_c + seg_d are chunk edges
     double inv_c;             // 1.0 / seg_c
+    // device-side redo: only the block pairs p with only_pairs[p] != 0 run (nullptr: all).  The peak pick
+    // marks the pairs of the chunks whose certificate failed (SparseScores::redo_pairs), K3 then runs once
+    // more for those pairs with every run written, from the work matrix it still has.
+    const int* only_pairs;
 };
 // accumulate: the scores are added to what job.dst holds (every run written; f32 work matrix only)
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
@@ -101,7 +105,7 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 constexpr int kInlinePeaks = 4;
 struct SegHeader {
     int n;
-    int overflow;      // bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks; bit 1: theta too high for this chunk;
+    int overflow;      // bit 0: more than AM_MAX_PEAKS_PER_CHUNK peaks; bit 1: a write threshold was too high for this chunk;
                        // bit 2: more than kInlinePeaks peaks and no room left in the spill arena
     float seg_min;     // (lower bound of the) chunk minimum, for adapting theta
     int arena_off;     // n > kInlinePeaks: the whole list sits at arena.base[arena_off .. arena_off + n)
@@ -122,6 +126,8 @@ struct SparseScores {
     const float* tile_theta;           // thresholds K3 used (the pick's certificate reads them)
     int hop, log_n2, log_n1;           // block geometry: score n of a block = row (n >> log_n2), column (n & (2^log_n2 - 1))
     double inv_hop;
+    int* redo_pairs;                   // per block pair: set by the pick when a chunk fed by the pair fails its certificate (or null)
+    unsigned char* fail_flags;         // host-visible, one per chunk of the launch: set when the chunk failed its certificate (or null)
 };
 // Hand-over of chunks with many candidate tiles from peaks_kernel to peaks_wide /
 // peaks_finish (device memory, one entry per chunk of the launch; list: AM_MAX_PEAKS_PER_CHUNK
@@ -148,10 +154,11 @@ hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len
                                  float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide);
 hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
                                    unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n);
+// only_failed: pick only the chunks whose header says "certificate failed" (after the device-side redo of K3)
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
-                        const WideState& wide);
+                        const WideState& wide, bool only_failed = false);
 // writes sumsq_parts(n) partial sums (one per workgroup) to d_parts
 int sumsq_parts(long long n);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts);

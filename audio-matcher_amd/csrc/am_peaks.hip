@@ -656,7 +656,8 @@ __device__ __forceinline__ bool tile_can_qualify(const float2* tiles, long long 
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
-             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide) {
+             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide,
+             int only_failed) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -678,6 +679,9 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
     if (tid == 0) { queue_n = 0; res_n = 0; overflow = 0; cand_n = 0; best_s = 0ull; wide.state[blockIdx.x] = 0; }
+    // second pick after a device-side redo of K3: only the chunks that failed their certificate take part
+    // (the others keep their header; their hand-over state is cleared so that peaks_wide / peaks_finish skip them)
+    if (only_failed && !(hdr[blockIdx.x].overflow & 2)) return;
     if (b - a < 3) {
         if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = 0.f; hdr[blockIdx.x].arena_off = -1; }
         return;
@@ -725,6 +729,10 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         th = fmaxf(fmaxf(th_s[0], th_s[1]), fmaxf(th_s[2], th_s[3]));
         if (!((th - seg_min) < min_prom)) {
             if (tid == 0) { hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 2; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1; }
+            // the block pairs that feed this chunk: K3 runs for them once more with every run written
+            if (sp.redo_pairs != nullptr)
+                for (long long q = (b0 >> 1) + tid; q <= (b1 >> 1); q += kPeakThreads) sp.redo_pairs[q] = 1;
+            if (tid == 0 && sp.fail_flags != nullptr) sp.fail_flags[blockIdx.x] = 1;
             return;
         }
     }
@@ -1252,10 +1260,10 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
-                        const WideState& wide) {
+                        const WideState& wide, bool only_failed) {
     if (nsegs <= 0) return hipSuccess;
     hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide);
+                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide, only_failed ? 1 : 0);
     if (wide.list != nullptr) {
         // both return at once for chunks that peaks_kernel finished itself (the usual case)
         hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,

@@ -842,7 +842,28 @@ def make_speechlike(am, device, s, h):
             "AR(1) noise (rho 0.9) under a 4 Hz x 20 s loud / quiet envelope (speech-like level changes); exact results")
 
 
-NON_WHITE = {"non_white_signal": make_tonal, "non_white_ar1": make_ar1, "non_white_speechlike": make_speechlike}
+def make_tonal_hits(am, device, s, h):
+    """A tonal needle (a 440 Hz tone under a slow envelope, a little noise) planted into white noise: the
+    background scores are tiny, but every hit comes with the needle's autocorrelation -- lobes of -0.98 / +0.96
+    half a period (50 samples) either side of the peak.  A chunk with a hit has a minimum near -1 that all
+    but one of the K3 tiles never sample: its write-threshold certificate fails."""
+    import numpy as np
+    rng = np.random.default_rng(13)
+    t = np.arange(s, dtype=np.float64)
+    env = 0.5 - 0.5 * np.cos(2 * np.pi * t / s)
+    needle = (0.2 * env * np.sin(2 * np.pi * 440.0 / SR * t)).astype(np.float32) + rng.uniform(-0.01, 0.01, s).astype(np.float32)
+    hay = rng.uniform(-0.25, 0.25, h).astype(np.float32)
+    plants = [t0 for t0 in plant_offsets(0) if t0 + s <= h]
+    for p0 in plants:
+        hay[p0:p0 + s] += needle
+    return (*_upload(am, device, needle, hay, s), plants,
+            "a tonal needle in white noise: every hit brings autocorrelation lobes of -0.98 with it (chunk minimum near -1 in the "
+            "chunks with a hit, background +-0.01): those chunks fail the write-threshold certificate and are redone on the device; "
+            "exact results")
+
+
+NON_WHITE = {"non_white_signal": make_tonal, "non_white_ar1": make_ar1, "non_white_speechlike": make_speechlike,
+             "hits_with_negative_lobes": make_tonal_hits}
 
 
 if __name__ == "__main__":

@@ -501,7 +501,7 @@ def test_needle_above_the_largest_transform(gpu, oracle):
 # ---------------------------------------------------------------------------
 # the non-white signals of bench.py against the checker
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["non_white_signal", "non_white_ar1", "non_white_speechlike"])
+@pytest.mark.parametrize("name", ["non_white_signal", "non_white_ar1", "non_white_speechlike", "hits_with_negative_lobes"])
 def test_non_white_generators_against_the_checker(gpu, oracle, name):
     """bench.py's three non-white signals (tone and drift, AR(1) noise, AR(1) under a speech-like
     envelope) at 20 minutes of 44.1 kHz audio with the 10 s needle: offsets, plateau ends, heights and
@@ -580,3 +580,55 @@ def test_plan_2_23_correlate_and_match(gpu, oracle):
         assert key(wide.match(hay, p)) == key(res[0])
     finally:
         gpu.set_option("dense_scores", 0)
+
+
+# ---------------------------------------------------------------------------
+# certificate failures inside a batch: redone on the device
+# ---------------------------------------------------------------------------
+def test_failed_certificates_in_a_batch_are_redone_on_the_device(gpu, oracle):
+    """Chunks whose minimum lies far below what the K3 tiles sampled (inverted copies of the needle: dips to -1 a few
+    scores wide) fail their certificate.  In a batch the pick marks the block pairs that feed them, K3 runs again
+    for those pairs with every run written and the chunks are picked again, all on the device; the results
+    equal the single calls' (which redo such chunks from the host) and the checker's, bit for bit, call after
+    call (the write threshold's history moves in between), also with a dip in every chunk."""
+    sr = 44100
+    s = 3 * sr
+    needle = oracle.synth_uniform(95, 0, 0, s)
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=3.0, distance_s=2.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+
+    def make(seed, dips, hits):
+        hay = oracle.synth_uniform(95, seed, 0, 400 * sr)
+        for t in dips:
+            hay[int(t * sr):int(t * sr) + s] -= needle
+        for t in hits:
+            hay[int(t * sr):int(t * sr) + s] += needle
+        return hay
+
+    hays = [make(1, (70.0,), (75.0, 150.0)),                              # one chunk with a dip
+            make(2, (), (20.0, 333.3)),                                     # none
+            make(3, (10.0, 70.0, 130.0, 190.0, 250.0, 310.0, 370.0), (45.0, 200.0)),   # a dip in every chunk
+            make(4, (199.0, 301.0), (200.5, 300.0))]
+    exps = [oracle.calc_chunks(sr, h, needle, p.chunk, p.overlap, 0.13, p.min_distance, 2.0) for h in hays]
+    assert [len(e) for e in exps] == [2, 2, 2, 2]
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in hays]
+    ptrs, lens = [b.ptr for b in bufs], [h.size for h in hays]
+    single = gpu.HipConvolve(needle)
+    want = [key(single.match_device(b.ptr, n, p)) for b, n in zip(bufs, lens)]
+    for got, exp in zip(want, exps):
+        assert [q[0] for q in got] == [e[0] for e in exp]
+    algo = gpu.HipConvolve(needle)
+    gpu.set_option("profile_mask", -1)
+    with gpu.Profile(0) as prof:
+        for _ in range(4):
+            res = algo.match_batch_device(ptrs, lens, p)
+            assert [key(r) for r in res] == want
+        k3_launches = prof.query("k3_cols_inv")[1]
+    assert k3_launches == 4 * 2 * len(hays)          # one K3 and one (mostly empty) redo launch per haystack: no host-side redo ran
+    res = algo.match_batch_device(ptrs[::-1], lens[::-1], p)
+    assert [key(r) for r in res] == want[::-1]
+    for r, e in zip(res[::-1], exps):
+        assert_same(r, e)
+    # i16 input and the half-precision levels go the same way
+    pool = gpu.Pool(needle, [0, 0])
+    assert [key(r) for r in pool.match_batch_device(ptrs, lens, p)] == want
+    pool.close()
