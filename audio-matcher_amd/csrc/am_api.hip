@@ -1106,7 +1106,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             ScanCfg cfg = scan.redo_cfg;
             cfg.margin = -1.0f;
             cfg.only_pairs = d_redo;
-            { ProfScope ps(c, KN_K3, c->stream2);
+            { ProfScope ps(c, KN_OTHER, c->stream2);   // (not under "k3_cols_inv": an all-but-empty launch that queues behind the next haystack's kernels)
               AM_HIP(launch_k3(c->stream2, scan.redo_job, scan.redo_npairs, scan.redo_work, scan.redo_pl, scan.redo_scale, cfg, scan.redo_half)); }
             ScanRequest again = scan;
             again.sparse.redo_pairs = nullptr; again.sparse.fail_flags = nullptr; again.bad = nullptr;
