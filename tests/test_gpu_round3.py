@@ -624,7 +624,8 @@ def test_failed_certificates_in_a_batch_are_redone_on_the_device(gpu, oracle):
             assert [key(r) for r in res] == want
         k3_launches, redo_launches = prof.query("k3_cols_inv")[1], prof.query("other")[1]
     # one K3 per haystack and call -- a host-side redo would launch more -- and one (mostly empty) device-side redo launch
-    assert k3_launches == 4 * len(hays) and redo_launches == 4 * len(hays)
+    # ("other" also holds the one launch that builds the needle's spectrum on its first use)
+    assert k3_launches == 4 * len(hays) and 4 * len(hays) <= redo_launches <= 4 * len(hays) + 1
     res = algo.match_batch_device(ptrs[::-1], lens[::-1], p)
     assert [key(r) for r in res] == want[::-1]
     for r, e in zip(res[::-1], exps):
