@@ -1048,6 +1048,15 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // (from the haystack's own work matrix: two alternate) and the chunk is picked again -- all on the
     // second stream, no host round trip.  (Single calls redo such a chunk from the host, below.)
     const bool device_redo = overlap && sparse_ok && !needle_is_segmented(h, o);
+    if (device_redo) {   // sized once for the haystack with the most block pairs: no pick of the batch waits for an allocation
+        long long most = 1;
+        for (size_t k = 0; k < n_hay; ++k) {
+            Geometry g{};
+            if (n_chunks[k] && plan_geometry(s, (long long)(lens[k] - s + 1), o, &g) == AM_OK) most = std::max(most, g.npairs);
+        }
+        for (int set = 0; set < 2; ++set)
+            if ((rc = c->redo_pairs[set].ensure(sizeof(int) * (size_t)most))) return rc;
+    }
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     auto chunk_events = [&](size_t k, int stage) {
         if (hooks.chunk_fn)
