@@ -1342,7 +1342,9 @@ __device__ __forceinline__ void k3_tile_h16(const Job& job, const PlanDev& pl, c
 #ifndef AM_K3_WGS
 #define AM_K3_WGS 3   // waves per SIMD the register allocation has to allow (= workgroups per CU for 256 threads; it uses 118 VGPRs: four fit)
 #endif
-template <int HALF, bool ACC = false>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
+// REDO only names the instantiation that the device-side redo launches (the same code: scan.only_pairs picks the
+// pairs), so that a kernel trace lists those all-but-empty launches apart from the pipeline's K3
+template <int HALF, bool ACC = false, int REDO = 0>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
 __global__ void __launch_bounds__(256, AM_K3_WGS)
 k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1538,7 +1540,7 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <int HALF, bool ACC = false>   // as in k1_cols_fwd_c512
+template <int HALF, bool ACC = false, int REDO = 0>   // as in k1_cols_fwd_c512
 __global__ void __launch_bounds__(512, 2)   // (uses 119 / 117 VGPRs: two workgroups per CU; a tighter bound makes the allocator spill)
 k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -1802,7 +1804,7 @@ k1_cols_fwd_c1024(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <bool ACC>   // ACC: add to what job.dst holds (needle partitioning, see k3_finish)
+template <bool ACC, int REDO = 0>   // ACC: add to what job.dst holds (needle partitioning, see k3_finish)
 __global__ void __launch_bounds__(1024)
 k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
     extern __shared__ float4 lds4[];
@@ -2132,6 +2134,13 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k1_cols_fwd_c1024<0>, kC1024Lds)
     AM_SET_LDS(k1_cols_fwd_c1024<1>, kC1024Lds)
     AM_SET_LDS(k3_cols_inv_c1024<false>, kC1024Lds)
+    AM_SET_LDS((k3_cols_inv_c1024<false, 1>), kC1024Lds)
+    AM_SET_LDS((k3_cols_inv_c512<0, false, 1>), kC512Lds)
+    AM_SET_LDS((k3_cols_inv_c512<1, false, 1>), kC512Lds)
+    AM_SET_LDS((k3_cols_inv_c512<2, false, 1>), kC512Lds)
+    AM_SET_LDS((k3_cols_inv_r16<0, false, 1>), kR16LdsK3)
+    AM_SET_LDS((k3_cols_inv_r16<1, false, 1>), kR16LdsK3)
+    AM_SET_LDS((k3_cols_inv_r16<2, false, 1>), kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_c1024<true>, kC1024Lds)
     AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
     AM_SET_LDS((k3_cols_inv_c512<0, true>), kC512Lds)
@@ -2231,6 +2240,23 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, int half, bool accumulate) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
+    if (scan.only_pairs != nullptr && !accumulate && plan_has_scan(pl)) {
+        // the device-side redo: the same kernels under names of their own
+        const dim3 g1((unsigned)npairs * (kN2 >> kColsLog));
+        if (plan_is_c1024(pl)) {
+            if (half) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((k3_cols_inv_c1024<false, 1>), g1, dim3(1024), kC1024Lds, st, job, work, pl, out_scale, scan);
+        } else if (plan_is_c512(pl)) {
+            if (half == 2) hipLaunchKernelGGL((k3_cols_inv_c512<2, false, 1>), g1, dim3(512), kC512Lds, st, job, work, pl, out_scale, scan);
+            else if (half) hipLaunchKernelGGL((k3_cols_inv_c512<1, false, 1>), g1, dim3(512), kC512Lds, st, job, work, pl, out_scale, scan);
+            else hipLaunchKernelGGL((k3_cols_inv_c512<0, false, 1>), g1, dim3(512), kC512Lds, st, job, work, pl, out_scale, scan);
+        } else {
+            if (half == 2) hipLaunchKernelGGL((k3_cols_inv_r16<2, false, 1>), g1, dim3(256), kR16LdsK3, st, job, work, pl, out_scale, scan);
+            else if (half) hipLaunchKernelGGL((k3_cols_inv_r16<1, false, 1>), g1, dim3(256), kR16LdsK3, st, job, work, pl, out_scale, scan);
+            else hipLaunchKernelGGL((k3_cols_inv_r16<0, false, 1>), g1, dim3(256), kR16LdsK3, st, job, work, pl, out_scale, scan);
+        }
+        return hipGetLastError();
+    }
     if (accumulate && half) return hipErrorInvalidValue;   // (the accumulating forms exist for the f32 work matrix only)
     if (accumulate && (plan_has_scan(pl)) && ((reinterpret_cast<uintptr_t>(job.dst) & 7) != 0 || (job.hop & 1) != 0)) return hipErrorInvalidValue;
     if (plan_is_c1024(pl)) {

@@ -32,7 +32,7 @@ res = {}
 for key, pat in KEYS.items():
     agg = {}
     for name, counters in vals.items():
-        if pat not in name:
+        if pat not in name or name.split("(")[0].rstrip().endswith(", 1>"):   # (skip the device-side redo's K3 instantiations)
             continue
         for cname, lst in counters.items():
             gmax = max(g for _, g in lst)

@@ -41,6 +41,8 @@ def main():
         def pick(vals):
             best = []
             for name, lst in vals.items():
+                if name.split("(")[0].rstrip().endswith(", 1>"):
+                    continue   # (the device-side redo's all-but-empty K3 launches run under instantiations of their own)
                 if any(p_ in name for p_ in ((pat,) if isinstance(pat, str) else pat)):
                     gmax = max(g for _, g in lst)          # full-size launches only (skip the 1-pair needle launch)
                     best += [v for v, g in lst if g == gmax]
