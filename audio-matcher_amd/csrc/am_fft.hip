@@ -635,12 +635,15 @@ __device__ __forceinline__ void k2_forward3(const K2Lane& k, const float4* lds4,
 
 // pointwise multiply (pairwise_mult_in_place, audio_matcher.rs:432-438)
 // q = z * h in the order the inverse wants (z[r] holds frequency brev(r); the inverse takes natural order)
+template <bool HALF>
 __device__ __forceinline__ void k2_multiply(const float2 (&z)[32], const float4 (&h)[16], float hscale, float2 (&q)[32]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        // hscale != 1 only with half storage: keeps the stored values well inside f16's range
-        q[brev<32>(2 * i)] = cmul(z[2 * i], make_float2(h[i].x * hscale, h[i].y * hscale));
-        q[brev<32>(2 * i + 1)] = cmul(z[2 * i + 1], make_float2(h[i].z * hscale, h[i].w * hscale));
+        // hscale: half storage only (it keeps the stored values well inside f16's range); the f32 form
+        // does not spend 64 multiplications by one on it
+        const float s = HALF ? hscale : 1.0f;
+        q[brev<32>(2 * i)] = cmul(z[2 * i], HALF ? make_float2(h[i].x * s, h[i].y * s) : make_float2(h[i].x, h[i].y));
+        q[brev<32>(2 * i + 1)] = cmul(z[2 * i + 1], HALF ? make_float2(h[i].z * s, h[i].w * s) : make_float2(h[i].z, h[i].w));
     }
 }
 // The same with the spectrum row fetched a quarter at a time (needle-group kernel: z
@@ -777,7 +780,7 @@ k2_rows_r16(float2* __restrict__ work, const float2* __restrict__ hc, float2* __
     const __amdgpu_buffer_rsrc_t rdst = !hc_out ? rrow
         : HALF ? make_rsrc(reinterpret_cast<unsigned*>(hc_out) + row_off, kN2 * 4) : make_rsrc(hc_out + row_off, kN2 * 8);
     float2 q[32];
-    k2_multiply(z, h, hscale, q);
+    k2_multiply<HALF>(z, h, hscale, q);
     k2_inverse<HALF>(k, q, lds4, rdst);
 }
 
@@ -902,6 +905,148 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
 #pragma unroll
     for (int a = 0; a < 16; ++a)
         buf_store_u2(rdst, k.voff / 2, a * 2048, make_uint2(h2_bits(x0[brev<16>(a)]), h2_bits(x1[brev<16>(a)])));
+}
+
+// K2 in f32 with the row exchanged one PLANE at a time (the points a thread holds as x0, then those it
+// holds as x1: every exchange of the kernel keeps the two apart, see k2_forward12 / k2_inverse), in the
+// 8-byte layout of k2_rows_h16: 34 KB of LDS instead of 64 and, with the needle-spectrum row fetched by
+// halves, at most 168 registers -- three workgroups per CU instead of two.  Why that matters: K2 is bound
+// by VALU issue, not by its stream (SQ counters, DESIGN.md section 5: 3292 VALU instructions per wave, the
+// SIMDs' VALU busy in 90 % of the kernel's cycles at one instruction per four cycles); one wave issues a
+// VALU instruction at most every eight cycles, two waves per SIMD reach one per four, three and more one
+// per 3.2 - 3.5 (tools/pkbench).  The two cross-wave exchanges cost three barriers each instead of one.
+#ifndef AM_K2_PLANES
+#define AM_K2_PLANES 1
+#endif
+#ifndef AM_K2P_WAVES
+#define AM_K2P_WAVES 3
+#endif
+#ifndef AM_K2P_RECOMPUTE
+#define AM_K2P_RECOMPUTE 1
+#endif
+__global__ void __launch_bounds__(256, AM_K2P_WAVES)
+k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst, PlanDev pl, unsigned npairs) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    unsigned row, slot;
+    k2_place(npairs, row, slot);
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
+    const __amdgpu_buffer_rsrc_t rdst = dst ? make_rsrc(dst + row_off, kN2 * 8) : rrow;   // in place, or a second work matrix
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + (size_t)row * (kN2 / 2), kN2 * 8);
+    const K2Lane k = k2_lane(pl);
+    const int t = k.t, hi = k.hi, cp = k.cp;
+    float2 x0[16], x1[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
+        const float4 v = buf_load4<AM_K2_LOAD_AUX>(rrow, k.voff, a * 4096);
+        x0[a] = make_float2(v.x, v.y);
+        x1[a] = make_float2(v.z, v.w);
+    }
+    // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1; exchange L1[a'][j] ----
+    dif<16, false>(x0);
+    twiddle_brev<16, false>(x0, k.wj0);
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) lds2[ap * kK2hSlab + t] = x0[brev<16>(ap)];
+    dif<16, false>(x1);
+    twiddle_brev<16, false>(x1, k.wj1);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x0[b] = lds2[hi * kK2hSlab + b * 16 + cp];
+    __syncthreads();
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) lds2[ap * kK2hSlab + t] = x1[brev<16>(ap)];
+    // ---- pass 2 over b (stride 32): a' = hi, c = 2cp, 2cp+1; twiddle W_512^(c*b') ----
+    dif<16, false>(x0);
+    twiddle_brev<16, false>(x0, k.wc0);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x1[b] = lds2[hi * kK2hSlab + b * 16 + cp];
+    // from here to the last exchange a slab (a' = hi) is touched by the wavefront of the threads with that hi only
+    wave_sync_lds();
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) lds2[hi * kK2hSlab + bp * 16 + (cp ^ bp)] = x0[brev<16>(bp)];   // row u = hi*16 + b', slot cp ^ b'
+    dif<16, false>(x1);
+    twiddle_brev<16, false>(x1, k.wc1);
+    wave_sync_lds();
+    // ---- pass 3 over c (32 contiguous): thread owns row u = t; z[r] = frequency brev(r) of that row ----
+    float2 z[32];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[2 * i] = lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)];
+    wave_sync_lds();
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) lds2[hi * kK2hSlab + bp * 16 + (cp ^ bp)] = x1[brev<16>(bp)];
+    wave_sync_lds();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[2 * i + 1] = lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)];
+    // the needle-spectrum row (L2-resident) by quarters: two requested where only the 32 points of pass 3 are
+    // live, the others while the earlier ones are used (z, q and the whole row together do not fit 168 registers)
+    float4 ha[4], hb[4], hc4[4];
+    __builtin_amdgcn_sched_barrier(0);
+    k2_fetch_quarter(rh, k.voff, 0, ha);
+    k2_fetch_quarter(rh, k.voff, 1, hb);
+    __builtin_amdgcn_sched_barrier(0);
+    dif<32, false>(z);
+    __builtin_amdgcn_sched_barrier(0);
+    k2_fetch_quarter(rh, k.voff, 2, hc4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- multiply (pairwise_mult_in_place, audio_matcher.rs:432-438): q in the order the inverse wants ----
+    float2 q[32];
+    k2_multiply_quarter(z, ha, 0, q);
+    k2_fetch_quarter(rh, k.voff, 3, ha);
+    __builtin_amdgcn_sched_barrier(0);
+    k2_multiply_quarter(z, hb, 1, q);
+    k2_multiply_quarter(z, hc4, 2, q);
+    k2_multiply_quarter(z, ha, 3, q);
+    // ---- inverse pass 3 over c' ----
+    dif<32, true>(q);   // time index c at q[brev(c)]
+#if AM_K2P_RECOMPUTE
+    // (the twiddle powers of the inverse passes are those of the forward passes: left alone the compiler keeps
+    // some of them alive across the whole kernel, in scratch; recomputing them is cheaper)
+    K2Lane ki = k;
+    asm volatile("" : "+v"(ki.wj0.x), "+v"(ki.wj0.y), "+v"(ki.wj1.x), "+v"(ki.wj1.y),
+                      "+v"(ki.wc0.x), "+v"(ki.wc0.y), "+v"(ki.wc1.x), "+v"(ki.wc1.y));
+#else
+    const K2Lane& ki = k;
+#endif
+    wave_sync_lds();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)] = q[brev<32>(2 * i)];
+    wave_sync_lds();
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) x0[bp] = lds2[hi * kK2hSlab + bp * 16 + (cp ^ bp)];
+    wave_sync_lds();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)] = q[brev<32>(2 * i + 1)];
+    // ---- inverse pass 2 over b': conj twiddle first, then butterflies ----
+    twiddle_nat<16, true>(x0, ki.wc0);
+    dif<16, true>(x0);
+    wave_sync_lds();
+#pragma unroll
+    for (int bp = 0; bp < 16; ++bp) x1[bp] = lds2[hi * kK2hSlab + bp * 16 + (cp ^ bp)];
+    wave_sync_lds();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[hi * kK2hSlab + b * 16 + cp] = x0[brev<16>(b)];
+    twiddle_nat<16, true>(x1, ki.wc1);
+    dif<16, true>(x1);
+    __syncthreads();
+    // ---- inverse pass 1 over a' ----
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) x0[ap] = lds2[ap * kK2hSlab + t];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[hi * kK2hSlab + b * 16 + cp] = x1[brev<16>(b)];
+    twiddle_nat<16, true>(x0, ki.wj0);
+    dif<16, true>(x0);
+    __syncthreads();
+#pragma unroll
+    for (int ap = 0; ap < 16; ++ap) x1[ap] = lds2[ap * kK2hSlab + t];
+    twiddle_nat<16, true>(x1, ki.wj1);
+    dif<16, true>(x1);
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+        buf_store4<AM_K2_STORE_AUX>(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+                                                                       x1[brev<16>(a)].x, x1[brev<16>(a)].y));
 }
 
 __global__ void __launch_bounds__(256) spectrum_to_half_kernel(const float2* __restrict__ hc, long long n, float scale, unsigned* __restrict__ out) {
@@ -1080,7 +1225,8 @@ __device__ __forceinline__ bool run_has_chunk_edge(long long lo, long long c, lo
 // inverse 256-point column FFT, scaling, fused score scan, conditional raw-score
 // store.  Output index of row n1, column c is n1 * out_stride + c.
 struct K3Edges {
-    long long outA, outB, ecA, edA, ecB, edB;
+    long long outA, outB;
+    int relcA, reldA, relcB, reldB;   // one_edge: the block's chunk edges relative to its first score (INT_MAX: none in reach)
     bool one_edge;
 };
 // Chunk edges (scores i*c and i*c + d, audio_matcher.rs:104, 119).  With chunks longer
@@ -1091,19 +1237,22 @@ __device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan,
     K3Edges e;
     e.outA = blkA * job.hop; e.outB = blkB * job.hop;
     e.one_edge = scan.stats32 != nullptr && scan.seg_c >= (long long)job.hop + 32;
-    e.ecA = 0; e.edA = 0; e.ecB = 0; e.edB = 0;
+    e.relcA = e.reldA = e.relcB = e.reldB = 0x7fffffff;
     if (e.one_edge) {
         const long long c = scan.seg_c, d = scan.seg_d;
         const long long m = mod_recip(e.outA, c, scan.inv_c);
-        e.ecA = m == 0 ? e.outA : e.outA + (c - m);      // smallest i*c >= outA
-        e.edA = d;                                       // smallest i*c + d >= outA, i >= 0
+        const long long ecA = m == 0 ? e.outA : e.outA + (c - m);      // smallest i*c >= outA
+        long long edA = d;                                             // smallest i*c + d >= outA, i >= 0
         if (e.outA > d) {
             const long long m2 = mod_recip(e.outA - d, c, scan.inv_c);
-            e.edA = m2 == 0 ? e.outA : e.outA + (c - m2);
+            edA = m2 == 0 ? e.outA : e.outA + (c - m2);
         }
         // block B starts hop < c later: its first edge is the same one or the next
-        e.ecB = e.ecA >= e.outB ? e.ecA : e.ecA + c;
-        e.edB = e.edA >= e.outB ? e.edA : e.edA + c;
+        const long long ecB = ecA >= e.outB ? ecA : ecA + c;
+        const long long edB = edA >= e.outB ? edA : edA + c;
+        auto rel = [](long long edge, long long start) { const long long r = edge - start; return r < 0x7fffffffll ? (int)r : 0x7fffffff; };
+        e.relcA = rel(ecA, e.outA); e.reldA = rel(edA, e.outA);
+        e.relcB = rel(ecB, e.outB); e.reldB = rel(edB, e.outB);
     }
     return e;
 }
@@ -1115,13 +1264,14 @@ __device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan,
 // needle is the sum of the correlations with its segments, each on a shifted source).  Every score is written
 // and the fused scan is left out -- scan and accumulation together do not fit the 128 registers of the
 // 1024-thread kernel (over a thousand spilled values); the sums get their summary from tile_stats instead.
-template <int HB, typename T, bool ACC = false>
+// SCALED: the caller has folded out_scale into the transform (its first twiddle), the values are scores already.
+template <int HB, typename T, bool ACC = false, bool SCALED = false>
 __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, const K3Edges& ed, float2* lds2,
                                           int n2_0, int out_stride, int t, long long blkA, long long blkB,
                                           float out_scale, const T (&x0)[16], const T (&x1)[16]) {
     const int hi = t >> 4, cp = t & 15;
     const long long col = n2_0 + 2 * cp;
-    const long long outA = ed.outA, outB = ed.outB, ecA = ed.ecA, edA = ed.edA, ecB = ed.ecB, edB = ed.edB;
+    const long long outA = ed.outA, outB = ed.outB;
     const bool one_edge = ed.one_edge;
     const bool dst8 = ((reinterpret_cast<uintptr_t>(job.dst) & 7) == 0) && ((job.hop & 1) == 0);
     long long limA = job.out_count - outA; if (limA > job.hop) limA = job.hop;
@@ -1131,30 +1281,36 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
         const T v0 = x0[brev<16>(a)], v1 = x1[brev<16>(a)];
-        sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
-        sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
+        if (SCALED) {
+            sa0[a] = v0.x; sa1[a] = v1.x;
+            sb0[a] = v0.y; sb1[a] = v1.y;
+        } else {
+            sa0[a] = v0.x * out_scale; sa1[a] = v1.x * out_scale;
+            sb0[a] = v0.y * out_scale; sb1[a] = v1.y * out_scale;
+        }
     }
-    // which of this thread's 16 rows leave the chip as raw scores (bit a = row a * 2^HB + hi), per block
-    unsigned wantA = 0xFFFFu, wantB = 0xFFFFu;
+    // which of this thread's 16 rows leave the chip as raw scores, per block: bit 4 * (a & 7) of word a >> 3 = row
+    // a * 2^HB + hi (the layout the wavefront's ballot has once it is shifted by hi & 3, see below)
+    unsigned wantA[2] = {0x11111111u, 0x11111111u}, wantB[2] = {0x11111111u, 0x11111111u};
     if (!ACC && scan.stats32 != nullptr) {   // (the accumulating form writes plain scores: its sums are summarised by tile_stats)
         // ---- fused score scan: (min,max) per 32 consecutive scores ------------
         // this thread owns the run of row n1 = row (scores row*out_stride + n2_0 .. +31 of both blocks)
         const int row = scan_row_of<HB>(t);
-        const long long rowrun = (long long)row * out_stride + n2_0;
+        const int rowrun = row * out_stride + n2_0;   // (below the block length: 32-bit arithmetic from here on)
         // Every run is wholly valid or wholly invalid, except in the block that holds
         // the end of the score array.
-        const long long leftA = limA - rowrun, leftB = limB - rowrun;
+        const int leftA = (int)limA - rowrun, leftB = (int)limB - rowrun;
         const bool wholeA = leftA >= 32 || leftA <= 0, wholeB = leftB >= 32 || leftB <= 0;
         const float4* lds4 = reinterpret_cast<const float4*>(lds2);
         float rmnA, rmxA, rmnB, rmxB;
         __syncthreads();   // the column exchange above is finished with the tile (it crosses wavefronts)
         scan_put<HB>(lds2, hi, cp, sa0, sa1);
         wave_sync_lds();   // a row is written and read by lanes of one wavefront
-        scan_row_minmax<HB>(lds4, row, wholeA, (int)(leftA < 32 ? leftA : 32), rmnA, rmxA);
+        scan_row_minmax<HB>(lds4, row, wholeA, leftA < 32 ? leftA : 32, rmnA, rmxA);
         wave_sync_lds();
         scan_put<HB>(lds2, hi, cp, sb0, sb1);
         wave_sync_lds();
-        scan_row_minmax<HB>(lds4, row, wholeB, (int)(leftB < 32 ? leftB : 32), rmnB, rmxB);
+        scan_row_minmax<HB>(lds4, row, wholeB, leftB < 32 ? leftB : 32, rmnB, rmxB);
         // Raw scores leave the chip only for RUNS that can matter to the peak pick: a run whose maximum
         // reaches the tile's write threshold, or one that straddles a chunk edge.  The threshold is the
         // tile's own: its 2^(HB+4) runs are spread evenly over the whole block (one every out_stride
@@ -1181,10 +1337,9 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         const bool dense = scan.margin < 0.0f;
         const float thA = dense ? -FLT_MAX : fminf(fminf(tminA, tminB), scan.hist_min) + scan.margin, thB = thA;
         bool edgeA, edgeB;
-        if (one_edge) {
-            const unsigned long long loA = (unsigned long long)(outA + rowrun), loB = (unsigned long long)(outB + rowrun);
-            edgeA = leftA > 0 && ((unsigned long long)ecA - loA <= 31ull || (unsigned long long)edA - loA <= 31ull);
-            edgeB = leftB > 0 && ((unsigned long long)ecB - loB <= 31ull || (unsigned long long)edB - loB <= 31ull);
+        if (one_edge) {   // edge positions relative to the block start, INT_MAX when beyond any run of the block
+            edgeA = leftA > 0 && ((unsigned)(ed.relcA - rowrun) <= 31u || (unsigned)(ed.reldA - rowrun) <= 31u);
+            edgeB = leftB > 0 && ((unsigned)(ed.relcB - rowrun) <= 31u || (unsigned)(ed.reldB - rowrun) <= 31u);
         } else {
             edgeA = leftA > 0 && run_has_chunk_edge(outA + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
             edgeB = leftB > 0 && run_has_chunk_edge(outB + rowrun, scan.seg_c, scan.seg_d, scan.inv_c);
@@ -1193,12 +1348,9 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         // The owner of row a * 2^HB + hi is lane (a << 2) | (hi & 3) of the wavefront that holds the column
         // owners (hi, *) (scan_row_of): the row's 16 writers read its decision out of a ballot.
         const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
-        wantA = 0u; wantB = 0u;
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            wantA |= (unsigned)((ba >> ((a << 2) | (hi & 3))) & 1ull) << a;
-            wantB |= (unsigned)((bb >> ((a << 2) | (hi & 3))) & 1ull) << a;
-        }
+        const unsigned sh = (unsigned)hi & 3u;
+        wantA[0] = ((unsigned)ba >> sh) & 0x11111111u; wantA[1] = ((unsigned)(ba >> 32) >> sh) & 0x11111111u;
+        wantB[0] = ((unsigned)bb >> sh) & 0x11111111u; wantB[1] = ((unsigned)(bb >> 32) >> sh) & 0x11111111u;
         // what was written, for the peak pick: the threshold per (block, tile) and the wavefront's ballot
         // (bit (a << 2) | j = row a * 2^HB + 4 w + j of the tile) per (block, tile, wavefront)
         const long long tileA = blkA * (out_stride >> kColsLog) + ((unsigned)n2_0 >> kColsLog), tileB = tileA + (out_stride >> kColsLog);
@@ -1213,10 +1365,10 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
         if (leftA > 0) scan.stats32[(outA + rowrun) >> 5] = make_float2(rmnA, rmxA);
         if (leftB > 0) scan.stats32[(outB + rowrun) >> 5] = make_float2(rmnB, rmxB);
     }
-    if (wantA) {
+    if (wantA[0] | wantA[1]) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            if (!((wantA >> a) & 1u)) continue;
+            if (!((wantA[a >> 3] >> ((a & 7) * 4)) & 1u)) continue;
             const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
             // hop and out offsets are even whenever this kernel is used, so a pair is
             // valid or invalid as a whole except at the very end of the score array
@@ -1233,10 +1385,10 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
             if (ACC && (a & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (keeps the read-modify-writes from being hoisted all at once)
         }
     }
-    if (wantB) {
+    if (wantB[0] | wantB[1]) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            if (!((wantB >> a) & 1u)) continue;
+            if (!((wantB[a >> 3] >> ((a & 7) * 4)) & 1u)) continue;
             const long long n = (long long)(a * (1 << HB) + hi) * out_stride + col;
             if (dst8 && n + 1 < limB) {
                 float2* ptr = reinterpret_cast<float2*>(job.dst + outB + n);
@@ -1626,10 +1778,13 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
             x1[bt] = T{f1.x, f1.y};
         }
     } else {
-        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+        // buffer loads: one VGPR of address for all 16 (the row offsets, multiples of 2 MB, ride in SGPRs), so
+        // that the requests leave back to back instead of behind a 64-bit address addition each
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(work + ((size_t)slot << pl.logN) + n2_0, (unsigned)((N - n2_0) * 8));
+        const unsigned voff = (unsigned)k10 * (kN2 * 8u) + (unsigned)cp * 16u;
 #pragma unroll
         for (int bt = 0; bt < 16; ++bt) {   // rows k1 = k10 + 32*beta
-            const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(k10 + 32 * bt) * (kN2 / 2));
+            const float4 v = buf_load4<AM_K3_LOAD_NT ? 2 : 0>(rin, voff, (unsigned)bt * (32u * kN2 * 8u));
             x0[bt] = T{v.x, v.y};
             x1[bt] = T{v.z, v.w};
         }
@@ -1637,8 +1792,11 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     const K3Edges ed = k3_edges(job, scan, blkA, blkB);
     const float2 w512 = pl.tw1[hi];
     {
-        const float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
-        const float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
+        // out_scale rides on the pipeline twiddle: everything behind it is linear, the scan sees scores
+        float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
+        float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
+        base0.x *= out_scale; base0.y *= out_scale;
+        base1.x *= out_scale; base1.y *= out_scale;
         const float2 step0 = tw_big(pl, (n2 * 32u) & maskN);
         const float2 step1 = tw_big(pl, ((n2 + 1u) * 32u) & maskN);
         twiddle_chain<16, true, false>(x0, base0, step0);
@@ -1678,7 +1836,7 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     twiddle_nat<16, true>(x1, w512);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*32 + b
     dif<16, true>(x1);
-    k3_finish<5, T, ACC>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_finish<5, T, ACC, true>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // ===========================================================================
@@ -2206,6 +2364,8 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
                                pl, (unsigned)npairs, pre);
         } else if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
+        else if (AM_K2_PLANES) hipLaunchKernelGGL(k2_rows_r16_planes, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st, work, hc,
+                                                  dst, pl, (unsigned)npairs);
         else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                 dst, pl, (unsigned)npairs, 1.0f);
     } else {
