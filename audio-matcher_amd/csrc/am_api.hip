@@ -264,11 +264,34 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     const int logLo = (logN + 1) / 2;
     const size_t n1h = (size_t)1 << (logN1 - 1), n2h = (size_t)1 << (logN2 - 1);
     const size_t nlo = (size_t)1 << logLo, nhi = (size_t)1 << (logN - logLo);
-    std::vector<float2> host(n1h + n2h + nlo + nhi);
+    // float2 tables, then the float4 ones (see PlanDev): offsets in float2 units, the float4 part 16-byte aligned
+    const size_t f2count = (n1h + n2h + nlo + nhi + 1) & ~(size_t)1;
+    const size_t nk2j = logN2 == 13 ? 2 * 256 : 0, nk2c = logN2 == 13 ? 2 * 16 : 0;
+    std::vector<float2> host(f2count + 2 * (nlo + nhi + nk2j + nk2c));
     fill_twiddles(host, 0, n1h, (double)(1u << logN1), 1.0);
     fill_twiddles(host, n1h, n2h, (double)(1u << logN2), 1.0);
     fill_twiddles(host, n1h + n2h, nlo, (double)((size_t)1 << logN), 1.0);
     fill_twiddles(host, n1h + n2h + nlo, nhi, (double)((size_t)1 << logN), (double)nlo);
+    auto tw = [](double num, double denom) {
+        const double ang = -2.0 * M_PI * std::fmod(num, denom) / denom;
+        return make_float2((float)std::cos(ang), (float)std::sin(ang));
+    };
+    const double dN = (double)((size_t)1 << logN);
+    size_t o = f2count;
+    const size_t o_lo4 = o;
+    for (size_t k = 0; k < nlo; ++k) { host[o++] = tw((double)k, dN); host[o++] = tw(4.0 * (double)k, dN); }
+    const size_t o_hi4 = o;
+    for (size_t k = 0; k < nhi; ++k) { host[o++] = tw((double)k * (double)nlo, dN); host[o++] = tw(4.0 * (double)k * (double)nlo, dN); }
+    const size_t o_k2j = o;
+    for (size_t t = 0; t < nk2j / 2; ++t) {
+        host[o++] = tw(2.0 * t, 8192.0); host[o++] = tw(2.0 * t + 1.0, 8192.0);
+        host[o++] = tw(8.0 * t, 8192.0); host[o++] = tw(8.0 * t + 4.0, 8192.0);
+    }
+    const size_t o_k2c = o;
+    for (size_t cidx = 0; cidx < nk2c / 2; ++cidx) {
+        host[o++] = tw(32.0 * cidx, 8192.0); host[o++] = tw(32.0 * cidx + 16.0, 8192.0);
+        host[o++] = tw(128.0 * cidx, 8192.0); host[o++] = tw(128.0 * cidx + 64.0, 8192.0);
+    }
     AM_HIP(hipMalloc((void**)&p.tables, host.size() * sizeof(float2)));
     AM_HIP(copy_on_stream(c, p.tables, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice));
     p.dev.logN = logN; p.dev.logN1 = logN1; p.dev.logN2 = logN2; p.dev.logLo = logLo;
@@ -276,6 +299,10 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     p.dev.tw2 = p.tables + n1h;
     p.dev.twlo = p.tables + n1h + n2h;
     p.dev.twhi = p.tables + n1h + n2h + nlo;
+    p.dev.twlo4 = reinterpret_cast<const float4*>(p.tables + o_lo4);
+    p.dev.twhi4 = reinterpret_cast<const float4*>(p.tables + o_hi4);
+    p.dev.k2j = nk2j ? reinterpret_cast<const float4*>(p.tables + o_k2j) : nullptr;
+    p.dev.k2c = nk2c ? reinterpret_cast<const float4*>(p.tables + o_k2c) : nullptr;
     auto ins = c->plans.emplace(logN, p);
     *out = &ins.first->second;
     return AM_OK;

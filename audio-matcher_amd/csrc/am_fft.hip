@@ -60,6 +60,13 @@ __device__ __forceinline__ float2 tw_big(const PlanDev& pl, unsigned m) {
     return cmul(pl.twhi[m >> pl.logLo], pl.twlo[m & ((1u << pl.logLo) - 1u)]);
 }
 
+// W_N^m and W_N^(4m) through the tables that hold every entry's fourth power beside it: the same two fetches
+__device__ __forceinline__ void tw_big_pair(const PlanDev& pl, unsigned m, float2& w, float2& w4) {
+    const float4 h = pl.twhi4[m >> pl.logLo], l = pl.twlo4[m & ((1u << pl.logLo) - 1u)];
+    w = cmul(make_float2(h.x, h.y), make_float2(l.x, l.y));
+    w4 = cmul(make_float2(h.z, h.w), make_float2(l.z, l.w));
+}
+
 // ===========================================================================
 // Register-resident radix-R DIF butterflies (R <= 32), natural order in,
 // bit-reversed order out: X[k] ends up in x[brev(k)].
@@ -273,6 +280,52 @@ __device__ __forceinline__ void twiddle_brev(T* x, float2 w) { twiddle_apply<R, 
 template <int R, bool CONJ, typename T>
 __device__ __forceinline__ void twiddle_nat(T* x, float2 w) { twiddle_apply<R, CONJ, false>(x, w); }
 
+// The same from TWO table entries, w and w4 = w^4: w^e = (w^4)^(e >> 2) * w^(e & 3).  A table entry is
+// rounded to f32 (0.3 eps rms per component) and a power e carries e times that error, on top of the
+// products' own roundings: from w alone the 15 powers are 3.6 eps rms off (16 eps at worst), from w and
+// w^4 1.1 eps (5 at worst) -- and the twiddles' error is what bounds the transforms' (DESIGN.md section 3,
+// the reference's correlation KAT).  13 products instead of 14, four live powers instead of eight.
+__device__ __forceinline__ float2 tw_as(float2 v, float2) { return v; }
+__device__ __forceinline__ h2 tw_as(float2 v, h2) { return to_h2(v); }
+__device__ __forceinline__ p2 tw_as(float2 v, p2) { return to_p2(v); }
+template <int R, bool CONJ, bool BREV, typename T>
+__device__ __forceinline__ void twiddle_apply(T* x, float2 w, float2 w4) {
+    static_assert(R == 16, "powers 1..15 from w and w^4");
+    if (CONJ) { w.y = -w.y; w4.y = -w4.y; }
+    float2 lo[4];
+    lo[1] = w; lo[2] = cmul(w, w); lo[3] = cmul(lo[2], w);
+    float2 g = w4;   // w^(4 * grp)
+#pragma unroll
+    for (int e = 1; e < R; ++e) {
+        if ((e & 3) == 0 && e > 4) g = cmul(g, w4);
+        const float2 v = e < 4 ? lo[e] : (e & 3) == 0 ? g : cmul(g, lo[e & 3]);
+        x[BREV ? brev<R>(e) : e] = cmul(x[BREV ? brev<R>(e) : e], tw_as(v, T{}));
+    }
+}
+template <int R, bool CONJ, typename T>
+__device__ __forceinline__ void twiddle_brev(T* x, float2 w, float2 w4) { twiddle_apply<R, CONJ, true>(x, w, w4); }
+template <int R, bool CONJ, typename T>
+__device__ __forceinline__ void twiddle_nat(T* x, float2 w, float2 w4) { twiddle_apply<R, CONJ, false>(x, w, w4); }
+// x[idx(e)] *= base * step^e with step4 = step^4 from the table as well: four runs of three products
+// off the bases base * step4^k instead of one run of fifteen (the same 15 products)
+template <int R, bool CONJ, bool BREV, typename T>
+__device__ __forceinline__ void twiddle_chain(T* x, float2 base, float2 step, float2 step4) {
+    static_assert(R == 16, "four runs of four");
+    if (CONJ) { base.y = -base.y; step.y = -step.y; step4.y = -step4.y; }
+    float2 g = base;
+#pragma unroll
+    for (int k = 0; k < R; k += 4) {
+        if (k) g = cmul(g, step4);
+        float2 c = g;
+        x[BREV ? brev<R>(k) : k] = cmul(x[BREV ? brev<R>(k) : k], tw_as(c, T{}));
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            c = cmul(c, step);
+            x[BREV ? brev<R>(k + j) : k + j] = cmul(x[BREV ? brev<R>(k + j) : k + j], tw_as(c, T{}));
+        }
+    }
+}
+
 // 16-byte buffer accesses: one VGPR of address for a whole unrolled sequence
 // (per-access offsets live in SGPRs / immediates).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -404,15 +457,17 @@ __device__ __forceinline__ float2 load2_padded(const void* __restrict__ src, lon
 // the table lookups of one tile: W_256^b for the pass boundary and W_N^(n2*a'), W_N^(16*n2)
 // for the pipeline twiddle (k1 = a' + 16*b', a' = hi), requested before the samples so that
 // their latency overlaps the streaming loads
-struct K1Twiddles { float2 w256, base0, base1, step0, step1; };
+// (w256q, step0q, step1q: the fourth powers, see twiddle_apply(x, w, w4))
+struct K1Twiddles { float2 w256, w256q, base0, base1, step0, step1, step0q, step1q; };
 __device__ __forceinline__ K1Twiddles k1_twiddles(const PlanDev& pl, long long col, int hi) {
     const unsigned maskN = (unsigned)((1ll << pl.logN) - 1);
     K1Twiddles w;
     w.w256 = pl.tw1[hi];
+    w.w256q = pl.tw1[4 * hi];
     w.base0 = tw_big(pl, ((unsigned)col * (unsigned)hi) & maskN);
     w.base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)hi) & maskN);
-    w.step0 = tw_big(pl, ((unsigned)col * 16u) & maskN);
-    w.step1 = tw_big(pl, (((unsigned)col + 1u) * 16u) & maskN);
+    tw_big_pair(pl, ((unsigned)col * 16u) & maskN, w.step0, w.step0q);
+    tw_big_pair(pl, (((unsigned)col + 1u) * 16u) & maskN, w.step1, w.step1q);
     return w;
 }
 // pass 1 ownership: rows n1 = a*16 + hi of columns col, col+1 (sample index n1 * in_stride + col
@@ -444,8 +499,8 @@ __device__ __forceinline__ void k1_load(const Job& job, long long col, int in_st
 __device__ __forceinline__ void k1_transform(const K1Twiddles& w, float2* lds2, int hi, int cp, float2 (&x0)[16], float2 (&x1)[16]) {
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, w.w256);   // W_256^(b*a')
-    twiddle_brev<16, false>(x1, w.w256);
+    twiddle_brev<16, false>(x0, w.w256, w.w256q);   // W_256^(b*a')
+    twiddle_brev<16, false>(x1, w.w256, w.w256q);
     // Exchange between the two passes, one column of the pair at a time so that a
     // workgroup needs 34 KB of LDS (row stride 17 keeps the 8-byte reads of rows
     // 16 apart on disjoint banks): pass 2 owns a' = hi, b = 0..15.
@@ -463,8 +518,8 @@ __device__ __forceinline__ void k1_transform(const K1Twiddles& w, float2* lds2, 
     dif<16, false>(x0);
     dif<16, false>(x1);
     // k1 = a' + 16*b';  W_N^(n2*k1) = W_N^(n2*a') * (W_N^(16*n2))^b'
-    twiddle_chain<16, false, true>(x0, w.base0, w.step0);
-    twiddle_chain<16, false, true>(x1, w.base1, w.step1);
+    twiddle_chain<16, false, true>(x0, w.base0, w.step0, w.step0q);
+    twiddle_chain<16, false, true>(x1, w.base1, w.step1, w.step1q);
 }
 // K1: f32 window load (pad(), audio_matcher.rs:232-235, 422) + 256-point column
 // FFTs of 32 adjacent columns + twiddle W_N^(n2*k1); row k1 of the work matrix
@@ -565,14 +620,19 @@ struct K2Lane {
     int t, hi, cp;
     unsigned voff;               // byte offset of the thread's first float4 in a row
     float2 wj0, wj1, wc0, wc1;   // twiddle seeds of both pass boundaries
+    float2 qj0, qj1, qc0, qc1;   // and their fourth powers (see twiddle_apply(x, w, w4))
 };
-__device__ __forceinline__ K2Lane k2_lane(const PlanDev& pl) {
+__device__ __forceinline__ K2Lane k2_lane(const PlanDev& pl, int t = threadIdx.x) {
     K2Lane k;
-    k.t = threadIdx.x; k.hi = k.t >> 4; k.cp = k.t & 15;
+    k.t = t; k.hi = k.t >> 4; k.cp = k.t & 15;
     k.voff = (unsigned)k.t * 16u;
-    // fetched beside the row so that their (L2) latency is not exposed in the middle of the transform
-    k.wj0 = pl.tw2[2 * k.t]; k.wj1 = pl.tw2[2 * k.t + 1];
-    k.wc0 = pl.tw2[32 * k.cp]; k.wc1 = pl.tw2[32 * k.cp + 16];
+    // fetched beside the row so that their (L2) latency is not exposed in the middle of the transform:
+    // W_8192^(2t), ^(2t+1), ^(32 cp), ^(32 cp + 16) and their fourth powers, four 16-byte fetches (PlanDev::k2j, k2c)
+    const float4 j = pl.k2j[2 * k.t], jq = pl.k2j[2 * k.t + 1], c = pl.k2c[2 * k.cp], cq = pl.k2c[2 * k.cp + 1];
+    k.wj0 = make_float2(j.x, j.y); k.wj1 = make_float2(j.z, j.w);
+    k.qj0 = make_float2(jq.x, jq.y); k.qj1 = make_float2(jq.z, jq.w);
+    k.wc0 = make_float2(c.x, c.y); k.wc1 = make_float2(c.z, c.w);
+    k.qc0 = make_float2(cq.x, cq.y); k.qc1 = make_float2(cq.z, cq.w);
     return k;
 }
 
@@ -596,8 +656,8 @@ __device__ __forceinline__ void k2_forward12(const K2Lane& k, __amdgpu_buffer_rs
     // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1 ----
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, k.wj0);
-    twiddle_brev<16, false>(x1, k.wj1);
+    twiddle_brev<16, false>(x0, k.wj0, k.qj0);
+    twiddle_brev<16, false>(x1, k.wj1, k.qj1);
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap)   // L1[a'][j]
         lds4[ap * 256 + t] = make_float4(x0[brev<16>(ap)].x, x0[brev<16>(ap)].y,
@@ -612,8 +672,8 @@ __device__ __forceinline__ void k2_forward12(const K2Lane& k, __amdgpu_buffer_rs
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, k.wc0);
-    twiddle_brev<16, false>(x1, k.wc1);
+    twiddle_brev<16, false>(x0, k.wc0, k.qc0);
+    twiddle_brev<16, false>(x1, k.wc1, k.qc1);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp)   // L2 row u = a'*16 + b', slot cp ^ b'
@@ -696,8 +756,8 @@ __device__ __forceinline__ void k2_inverse(const K2Lane& k, float2 (&q)[32], flo
         x0[bp] = make_float2(v.x, v.y);
         x1[bp] = make_float2(v.z, v.w);
     }
-    twiddle_nat<16, true>(x0, k.wc0);
-    twiddle_nat<16, true>(x1, k.wc1);
+    twiddle_nat<16, true>(x0, k.wc0, k.qc0);
+    twiddle_nat<16, true>(x1, k.wc1, k.qc1);
     dif<16, true>(x0);
     dif<16, true>(x1);
     wave_sync_lds();   // this exchange stays inside one wavefront (rows 64w .. 64w+63 <-> threads of wave w)
@@ -713,8 +773,8 @@ __device__ __forceinline__ void k2_inverse(const K2Lane& k, float2 (&q)[32], flo
         x0[ap] = make_float2(v.x, v.y);
         x1[ap] = make_float2(v.z, v.w);
     }
-    twiddle_nat<16, true>(x0, k.wj0);
-    twiddle_nat<16, true>(x1, k.wj1);
+    twiddle_nat<16, true>(x0, k.wj0, k.qj0);
+    twiddle_nat<16, true>(x1, k.wj1, k.qj1);
     dif<16, true>(x0);
     dif<16, true>(x1);
     if (HALF) {
@@ -822,8 +882,8 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
     // ---- pass 1 over a ----
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, k.wj0);
-    twiddle_brev<16, false>(x1, k.wj1);
+    twiddle_brev<16, false>(x0, k.wj0, k.qj0);
+    twiddle_brev<16, false>(x1, k.wj1, k.qj1);
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap)
         ldsu[ap * kK2hSlab + t] = make_uint2(h2_bits(x0[brev<16>(ap)]), h2_bits(x1[brev<16>(ap)]));
@@ -837,8 +897,8 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, k.wc0);
-    twiddle_brev<16, false>(x1, k.wc1);
+    twiddle_brev<16, false>(x0, k.wc0, k.qc0);
+    twiddle_brev<16, false>(x1, k.wc1, k.qc1);
     wave_sync_lds();   // wave-local exchange: slab hi belongs to the wavefront of the threads with that hi
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp)   // row u = hi*16 + b' of the slab, slot cp ^ b'
@@ -882,8 +942,8 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
         x0[bp] = bits_h2(v.x);
         x1[bp] = bits_h2(v.y);
     }
-    twiddle_nat<16, true>(x0, k.wc0);
-    twiddle_nat<16, true>(x1, k.wc1);
+    twiddle_nat<16, true>(x0, k.wc0, k.qc0);
+    twiddle_nat<16, true>(x1, k.wc1, k.qc1);
     dif<16, true>(x0);
     dif<16, true>(x1);
     wave_sync_lds();
@@ -898,8 +958,8 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
         x0[ap] = bits_h2(v.x);
         x1[ap] = bits_h2(v.y);
     }
-    twiddle_nat<16, true>(x0, k.wj0);
-    twiddle_nat<16, true>(x1, k.wj1);
+    twiddle_nat<16, true>(x0, k.wj0, k.qj0);
+    twiddle_nat<16, true>(x1, k.wj1, k.qj1);
     dif<16, true>(x0);
     dif<16, true>(x1);
 #pragma unroll
@@ -921,35 +981,30 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
 #ifndef AM_K2P_WAVES
 #define AM_K2P_WAVES 3
 #endif
-#ifndef AM_K2P_RECOMPUTE
-#define AM_K2P_RECOMPUTE 1
-#endif
-__global__ void __launch_bounds__(256, AM_K2P_WAVES)
-k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst, PlanDev pl, unsigned npairs) {
-    extern __shared__ float4 lds4[];
-    float2* lds2 = reinterpret_cast<float2*>(lds4);
-    unsigned row, slot;
-    k2_place(npairs, row, slot);
-    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
-    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
-    const __amdgpu_buffer_rsrc_t rdst = dst ? make_rsrc(dst + row_off, kN2 * 8) : rrow;   // in place, or a second work matrix
-    const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + (size_t)row * (kN2 / 2), kN2 * 8);
-    const K2Lane k = k2_lane(pl);
+// row load, forward passes 1 and 2 and the exchange into pass 3's layout: z[r] = point r of the thread's row u = t
+template <bool HALF>
+__device__ __forceinline__ void k2p_forward(const K2Lane& k, __amdgpu_buffer_rsrc_t rrow, float2* lds2, float2 (&z)[32]) {
     const int t = k.t, hi = k.hi, cp = k.cp;
     float2 x0[16], x1[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) {   // elements a*512 + 2t, +1
-        const float4 v = buf_load4<AM_K2_LOAD_AUX>(rrow, k.voff, a * 4096);
-        x0[a] = make_float2(v.x, v.y);
-        x1[a] = make_float2(v.z, v.w);
+        if (HALF) {
+            const uint2 v = buf_load_u2(rrow, k.voff / 2, a * 2048);
+            x0[a] = unpack_h2(v.x);
+            x1[a] = unpack_h2(v.y);
+        } else {
+            const float4 v = buf_load4<AM_K2_LOAD_AUX>(rrow, k.voff, a * 4096);
+            x0[a] = make_float2(v.x, v.y);
+            x1[a] = make_float2(v.z, v.w);
+        }
     }
     // ---- pass 1 over a (stride 512), twiddle W_8192^(j*a'), j = 2t, 2t+1; exchange L1[a'][j] ----
     dif<16, false>(x0);
-    twiddle_brev<16, false>(x0, k.wj0);
+    twiddle_brev<16, false>(x0, k.wj0, k.qj0);
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) lds2[ap * kK2hSlab + t] = x0[brev<16>(ap)];
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x1, k.wj1);
+    twiddle_brev<16, false>(x1, k.wj1, k.qj1);
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; ++b) x0[b] = lds2[hi * kK2hSlab + b * 16 + cp];
@@ -958,7 +1013,7 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
     for (int ap = 0; ap < 16; ++ap) lds2[ap * kK2hSlab + t] = x1[brev<16>(ap)];
     // ---- pass 2 over b (stride 32): a' = hi, c = 2cp, 2cp+1; twiddle W_512^(c*b') ----
     dif<16, false>(x0);
-    twiddle_brev<16, false>(x0, k.wc0);
+    twiddle_brev<16, false>(x0, k.wc0, k.qc0);
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; ++b) x1[b] = lds2[hi * kK2hSlab + b * 16 + cp];
@@ -967,10 +1022,9 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
 #pragma unroll
     for (int bp = 0; bp < 16; ++bp) lds2[hi * kK2hSlab + bp * 16 + (cp ^ bp)] = x0[brev<16>(bp)];   // row u = hi*16 + b', slot cp ^ b'
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x1, k.wc1);
+    twiddle_brev<16, false>(x1, k.wc1, k.qc1);
     wave_sync_lds();
-    // ---- pass 3 over c (32 contiguous): thread owns row u = t; z[r] = frequency brev(r) of that row ----
-    float2 z[32];
+    // ---- pass 3 over c (32 contiguous): thread owns row u = t ----
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[2 * i] = lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)];
     wave_sync_lds();
@@ -979,36 +1033,21 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
     wave_sync_lds();
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[2 * i + 1] = lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)];
-    // the needle-spectrum row (L2-resident) by quarters: two requested where only the 32 points of pass 3 are
-    // live, the others while the earlier ones are used (z, q and the whole row together do not fit 168 registers)
-    float4 ha[4], hb[4], hc4[4];
-    __builtin_amdgcn_sched_barrier(0);
-    k2_fetch_quarter(rh, k.voff, 0, ha);
-    k2_fetch_quarter(rh, k.voff, 1, hb);
-    __builtin_amdgcn_sched_barrier(0);
-    dif<32, false>(z);
-    __builtin_amdgcn_sched_barrier(0);
-    k2_fetch_quarter(rh, k.voff, 2, hc4);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- multiply (pairwise_mult_in_place, audio_matcher.rs:432-438): q in the order the inverse wants ----
-    float2 q[32];
-    k2_multiply_quarter(z, ha, 0, q);
-    k2_fetch_quarter(rh, k.voff, 3, ha);
-    __builtin_amdgcn_sched_barrier(0);
-    k2_multiply_quarter(z, hb, 1, q);
-    k2_multiply_quarter(z, hc4, 2, q);
-    k2_multiply_quarter(z, ha, 3, q);
+}
+
+// inverse passes 3, 2, 1 of the product q and the row store
+template <bool HALF, int SAUX = AM_K2_STORE_AUX>
+__device__ __forceinline__ void k2p_inverse(const PlanDev& pl, float2 (&q)[32], float2* lds2, __amdgpu_buffer_rsrc_t rdst) {
+    // the lane's twiddle seeds are fetched again (L1 / L2 hits, in flight behind pass 3) instead of kept alive
+    // across the product: sixteen registers the multiply, the kernel's widest point, does not have
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const K2Lane ki = k2_lane(pl, t);
+    const int hi = ki.hi, cp = ki.cp;
+    const K2Lane& k = ki;
+    float2 x0[16], x1[16];
     // ---- inverse pass 3 over c' ----
     dif<32, true>(q);   // time index c at q[brev(c)]
-#if AM_K2P_RECOMPUTE
-    // (the twiddle powers of the inverse passes are those of the forward passes: left alone the compiler keeps
-    // some of them alive across the whole kernel, in scratch; recomputing them is cheaper)
-    K2Lane ki = k;
-    asm volatile("" : "+v"(ki.wj0.x), "+v"(ki.wj0.y), "+v"(ki.wj1.x), "+v"(ki.wj1.y),
-                      "+v"(ki.wc0.x), "+v"(ki.wc0.y), "+v"(ki.wc1.x), "+v"(ki.wc1.y));
-#else
-    const K2Lane& ki = k;
-#endif
     wave_sync_lds();
 #pragma unroll
     for (int i = 0; i < 16; ++i) lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)] = q[brev<32>(2 * i)];
@@ -1019,7 +1058,7 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
 #pragma unroll
     for (int i = 0; i < 16; ++i) lds2[hi * kK2hSlab + cp * 16 + (i ^ cp)] = q[brev<32>(2 * i + 1)];
     // ---- inverse pass 2 over b': conj twiddle first, then butterflies ----
-    twiddle_nat<16, true>(x0, ki.wc0);
+    twiddle_nat<16, true>(x0, ki.wc0, ki.qc0);
     dif<16, true>(x0);
     wave_sync_lds();
 #pragma unroll
@@ -1027,7 +1066,7 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
     wave_sync_lds();
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[hi * kK2hSlab + b * 16 + cp] = x0[brev<16>(b)];
-    twiddle_nat<16, true>(x1, ki.wc1);
+    twiddle_nat<16, true>(x1, ki.wc1, ki.qc1);
     dif<16, true>(x1);
     __syncthreads();
     // ---- inverse pass 1 over a' ----
@@ -1036,17 +1075,113 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[hi * kK2hSlab + b * 16 + cp] = x1[brev<16>(b)];
-    twiddle_nat<16, true>(x0, ki.wj0);
+    twiddle_nat<16, true>(x0, ki.wj0, ki.qj0);
     dif<16, true>(x0);
     __syncthreads();
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) x1[ap] = lds2[ap * kK2hSlab + t];
-    twiddle_nat<16, true>(x1, ki.wj1);
+    twiddle_nat<16, true>(x1, ki.wj1, ki.qj1);
     dif<16, true>(x1);
+    if (HALF) {
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+            buf_store_u2(rdst, k.voff / 2, a * 2048, make_uint2(pack_h2(x0[brev<16>(a)]), pack_h2(x1[brev<16>(a)])));
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 16; ++a)
-        buf_store4<AM_K2_STORE_AUX>(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
-                                                                       x1[brev<16>(a)].x, x1[brev<16>(a)].y));
+        buf_store4<SAUX>(rdst, k.voff, a * 4096, make_float4(x0[brev<16>(a)].x, x0[brev<16>(a)].y,
+                                                           x1[brev<16>(a)].x, x1[brev<16>(a)].y));
+}
+
+template <bool HALF>   // HALF: the work matrix holds __half2 points (half_pipeline = 1), the arithmetic stays f32
+__global__ void __launch_bounds__(256, AM_K2P_WAVES)
+k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst, PlanDev pl, unsigned npairs,
+                   float hscale) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    unsigned row, slot;
+    k2_place(npairs, row, slot);
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    // one point is 8 bytes (float2) or, with half storage, 4 bytes (__half2)
+    const __amdgpu_buffer_rsrc_t rrow = HALF ? make_rsrc(reinterpret_cast<unsigned*>(work) + row_off, kN2 * 4)
+                                             : make_rsrc(work + row_off, kN2 * 8);
+    // in place, or into a second work matrix
+    const __amdgpu_buffer_rsrc_t rdst = !dst ? rrow
+        : HALF ? make_rsrc(reinterpret_cast<unsigned*>(dst) + row_off, kN2 * 4) : make_rsrc(dst + row_off, kN2 * 8);
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(hc) + (size_t)row * (kN2 / 2), kN2 * 8);
+    const K2Lane k = k2_lane(pl);
+    float2 z[32];
+    k2p_forward<HALF>(k, rrow, lds2, z);
+    // the needle-spectrum row (L2-resident) by quarters: two requested where only the 32 points of pass 3 are
+    // live, the others while the earlier ones are used (z, q and the whole row together do not fit 168 registers)
+    float4 ha[4], hb[4], hc4[4];
+    __builtin_amdgcn_sched_barrier(0);
+    k2_fetch_quarter(rh, k.voff, 0, ha);
+    k2_fetch_quarter(rh, k.voff, 1, hb);
+    __builtin_amdgcn_sched_barrier(0);
+    dif<32, false>(z);   // z[r] = frequency brev(r) of the row
+    __builtin_amdgcn_sched_barrier(0);
+    k2_fetch_quarter(rh, k.voff, 2, hc4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- multiply (pairwise_mult_in_place, audio_matcher.rs:432-438): q in the order the inverse wants ----
+    // (hscale: half storage only -- it keeps the stored values well inside f16's range)
+    auto scaled = [&](float4 (&h)[4]) {
+        if (HALF) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h[i].x *= hscale; h[i].y *= hscale; h[i].z *= hscale; h[i].w *= hscale; }
+        }
+    };
+    float2 q[32];
+    scaled(ha);
+    k2_multiply_quarter(z, ha, 0, q);
+    k2_fetch_quarter(rh, k.voff, 3, ha);
+    __builtin_amdgcn_sched_barrier(0);
+    scaled(hb);
+    k2_multiply_quarter(z, hb, 1, q);
+    scaled(hc4);
+    k2_multiply_quarter(z, hc4, 2, q);
+    scaled(ha);
+    k2_multiply_quarter(z, ha, 3, q);
+    k2p_inverse<HALF>(pl, q, lds2, rdst);
+}
+
+// The needle-group kernel (below) on the same plane-by-plane exchanges.
+#ifndef AM_K2G_PLANES
+#define AM_K2G_PLANES 1
+#endif
+#ifndef AM_K2GP_WAVES
+#define AM_K2GP_WAVES 3
+#endif
+#ifndef AM_K2G_STORE_AUX
+// cache policy of the group kernels' eight write streams: 2 = nt.  With the plane-wise kernel at three waves per
+// SIMD nt stores take 6.05 ms per call of 32 needles x 22 pairs against 6.6 (and against 6.5 for the 64 KB form at
+// two waves per SIMD, where nt made no difference: profiles/r03/k2_group_ab.txt)
+#define AM_K2G_STORE_AUX 2
+#endif
+__global__ void __launch_bounds__(256, AM_K2GP_WAVES)
+k2_rows_r16_group_planes(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsigned npairs) {
+    extern __shared__ float4 lds4[];
+    float2* lds2 = reinterpret_cast<float2*>(lds4);
+    unsigned row, slot;
+    k2_place(npairs, row, slot);
+    const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+    const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 8);
+    const size_t hoff4 = (size_t)row * (kN2 / 2);
+    const K2Lane k = k2_lane(pl);
+    float2 z[32];
+    k2p_forward<false>(k, rrow, lds2, z);
+    dif<32, false>(z);
+#pragma unroll 1
+    for (int j = 0; j < grp.n; ++j) {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(reinterpret_cast<const float4*>(grp.hc[j]) + hoff4, kN2 * 8);
+        float4 hq[4];
+        k2_fetch_quarter(rh, k.voff, 0, hq);
+        float2 q[32];
+        k2_multiply_fetch(z, rh, k.voff, hq, q);
+        k2p_inverse<false, AM_K2G_STORE_AUX>(pl, q, lds2, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
+        __syncthreads();   // the last pass read slabs of every wave: finish before the next needle's exchanges overwrite them
+    }
 }
 
 __global__ void __launch_bounds__(256) spectrum_to_half_kernel(const float2* __restrict__ hc, long long n, float scale, unsigned* __restrict__ out) {
@@ -1069,9 +1204,6 @@ hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n
 // from 230 to 256 VGPRs plus 15 spilled ones (64 bytes of scratch per lane, reloaded inside the needle
 // loop): 2.16 ms per launch of 8 needles x 22 pairs with it, 1.60 ms without.
 #define AM_K2G_PREFETCH 0
-#endif
-#ifndef AM_K2G_STORE_AUX
-#define AM_K2G_STORE_AUX 0   // cache policy of the eight write streams (2 = nt)
 #endif
 __global__ void __launch_bounds__(256, 2)
 k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsigned npairs) {
@@ -1097,6 +1229,8 @@ k2_rows_r16_group(const float2* __restrict__ work, K2Group grp, PlanDev pl, unsi
         K2Lane kj = k;
         asm volatile("" : "+v"(kj.wj0.x), "+v"(kj.wj0.y), "+v"(kj.wj1.x), "+v"(kj.wj1.y),
                           "+v"(kj.wc0.x), "+v"(kj.wc0.y), "+v"(kj.wc1.x), "+v"(kj.wc1.y));
+        asm volatile("" : "+v"(kj.qj0.x), "+v"(kj.qj0.y), "+v"(kj.qj1.x), "+v"(kj.qj1.y),
+                          "+v"(kj.qc0.x), "+v"(kj.qc0.y), "+v"(kj.qc1.x), "+v"(kj.qc1.y));
         float2 q[32];
         k2_multiply_fetch(z, rh, k.voff, hq, q);
         if (AM_K2G_PREFETCH) {
@@ -1418,15 +1552,16 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     const long long col = n2_0 + 2 * cp;
     const K3Edges ed = k3_edges(job, scan, blkA, blkB);
     const unsigned maskN = (unsigned)(N - 1);
-    const float2 w256 = pl.tw1[hi];
+    const float2 w256 = pl.tw1[hi], w256q = pl.tw1[4 * hi];   // (fourth powers: see twiddle_apply(x, w, w4))
     {
         const unsigned n2 = (unsigned)col;
         float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
         float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
-        const float2 step0 = tw_big(pl, (n2 * 16u) & maskN);
-        const float2 step1 = tw_big(pl, ((n2 + 1) * 16u) & maskN);
-        twiddle_chain<16, true, false>(x0, base0, step0);
-        twiddle_chain<16, true, false>(x1, base1, step1);
+        float2 step0, step1, step0q, step1q;
+        tw_big_pair(pl, (n2 * 16u) & maskN, step0, step0q);
+        tw_big_pair(pl, ((n2 + 1) * 16u) & maskN, step1, step1q);
+        twiddle_chain<16, true, false>(x0, base0, step0, step0q);
+        twiddle_chain<16, true, false>(x1, base1, step1, step1q);
     }
     dif<16, true>(x0);   // b at x[brev(b)]
     dif<16, true>(x1);
@@ -1443,8 +1578,8 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     __syncthreads();
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) x1[ap] = lds2[(ap * 16 + hi) * 16 + cp];
-    twiddle_nat<16, true>(x0, w256);
-    twiddle_nat<16, true>(x1, w256);
+    twiddle_nat<16, true>(x0, w256, w256q);
+    twiddle_nat<16, true>(x1, w256, w256q);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
     k3_finish<4, float2, ACC>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
@@ -1569,9 +1704,9 @@ __device__ __forceinline__ int c512_idx3(int ap, int b, int cp) { return ap * kC
 static_assert((15 * kC512Slab3 + 31 * 16 + 16) * 8 <= kC512Lds, "K3's exchange fits the kernel's LDS");
 
 template <int KIND, int HALF>   // HALF: 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and f16 butterflies
-// (second argument: waves per SIMD.  The f32 forms use 124 / 126 VGPRs and fit twice per CU as they are; the
-// half-storage form would take 130 and run alone on its CU, so it is held to 128)
-__global__ void __launch_bounds__(512, HALF ? 4 : 2)
+// (second argument: waves per SIMD = two workgroups per CU: held to 128 VGPRs -- left alone the allocator takes
+// 130 - 150 and the kernel runs alone on its CU)
+__global__ void __launch_bounds__(512, 4)
 k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     extern __shared__ float4 lds4[];
     float2* lds2 = reinterpret_cast<float2*>(lds4);
@@ -1591,10 +1726,16 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     const long long col = (long long)n2_0 + 2 * cp;
     const unsigned maskN = (unsigned)(N - 1);
     const float2 w512 = pl.tw1[hi];                 // W_512^b
+    const float2 w512q = pl.tw1[4 * hi];            // (fourth powers: see twiddle_apply(x, w, w4))
     const float2 base0 = tw_big(pl, ((unsigned)col * (unsigned)k10) & maskN);
     const float2 base1 = tw_big(pl, (((unsigned)col + 1u) * (unsigned)k10) & maskN);
-    const float2 step0 = tw_big(pl, ((unsigned)col * 32u) & maskN);
-    const float2 step1 = tw_big(pl, (((unsigned)col + 1u) * 32u) & maskN);
+    // W_N^(32 n2) per column, and its fourth power: the f32 forms fetch the two behind the last pass (held from the
+    // start of the kernel like the other table values they push it past 128 registers)
+    float2 step0, step1, step0q, step1q;
+    if constexpr (HALF == 2) {
+        step0 = tw_big(pl, ((unsigned)col * 32u) & maskN);
+        step1 = tw_big(pl, (((unsigned)col + 1u) * 32u) & maskN);
+    }
     float2 x0[16], x1[16];
     if (fast) {
 #pragma unroll
@@ -1647,8 +1788,8 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
     dif<16, false>(x0);
     dif<16, false>(x1);
-    twiddle_brev<16, false>(x0, w512);   // W_512^(b*a')
-    twiddle_brev<16, false>(x1, w512);
+    twiddle_brev<16, false>(x0, w512, w512q);   // W_512^(b*a')
+    twiddle_brev<16, false>(x1, w512, w512q);
     // exchange, one column of the pair at a time; afterwards thread (a', half) holds
     // w[b] = x[b] + x[b+16] or (x[b] - x[b+16]) W_32^b, b = 0..15
     float2 y0[16], y1[16];
@@ -1669,11 +1810,15 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
         const float2 lo = lds2[c512_idx(ap, b, cp)], up = lds2[c512_idx(ap, b + 16, cp)];
         y1[b] = half ? mul_w32<false>(csub(lo, up), b) : cadd(lo, up);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    tw_big_pair(pl, ((unsigned)col * 32u) & maskN, step0, step0q);   // (in flight behind the last pass)
+    tw_big_pair(pl, (((unsigned)col + 1u) * 32u) & maskN, step1, step1q);
+    __builtin_amdgcn_sched_barrier(0);
     dif<16, false>(y0);   // beta at y[brev(beta)], b' = 2*beta + half
     dif<16, false>(y1);
     // W_N^(n2*k1) = W_N^(n2*k10) * (W_N^(32*n2))^beta
-    twiddle_chain<16, false, true>(y0, base0, step0);
-    twiddle_chain<16, false, true>(y1, base1, step1);
+    twiddle_chain<16, false, true>(y0, base0, step0, step0q);
+    twiddle_chain<16, false, true>(y1, base1, step1, step1q);
     if (HALF) {
         uint2* __restrict__ out2 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned*>(work) + ((size_t)blockIdx.y << pl.logN) + n2_0) + cp;
 #pragma unroll
@@ -1790,17 +1935,18 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
         }
     }
     const K3Edges ed = k3_edges(job, scan, blkA, blkB);
-    const float2 w512 = pl.tw1[hi];
+    const float2 w512 = pl.tw1[hi], w512q = pl.tw1[4 * hi];   // (fourth powers: see twiddle_apply(x, w, w4))
     {
         // out_scale rides on the pipeline twiddle: everything behind it is linear, the scan sees scores
         float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
         float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
         base0.x *= out_scale; base0.y *= out_scale;
         base1.x *= out_scale; base1.y *= out_scale;
-        const float2 step0 = tw_big(pl, (n2 * 32u) & maskN);
-        const float2 step1 = tw_big(pl, ((n2 + 1u) * 32u) & maskN);
-        twiddle_chain<16, true, false>(x0, base0, step0);
-        twiddle_chain<16, true, false>(x1, base1, step1);
+        float2 step0, step1, step0q, step1q;
+        tw_big_pair(pl, (n2 * 32u) & maskN, step0, step0q);
+        tw_big_pair(pl, ((n2 + 1u) * 32u) & maskN, step1, step1q);
+        twiddle_chain<16, true, false>(x0, base0, step0, step0q);
+        twiddle_chain<16, true, false>(x1, base1, step1, step1q);
     }
     dif<16, true>(x0);   // inverse over beta: branch value b at x[brev(b)], b = 0..15
     dif<16, true>(x1);
@@ -1832,8 +1978,8 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
         const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
         x1[a2] = add_signed(u, v, sgn, T{});
     }
-    twiddle_nat<16, true>(x0, w512);   // conj(W_512^(b*a'))
-    twiddle_nat<16, true>(x1, w512);
+    twiddle_nat<16, true>(x0, w512, w512q);   // conj(W_512^(b*a'))
+    twiddle_nat<16, true>(x1, w512, w512q);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*32 + b
     dif<16, true>(x1);
     k3_finish<5, T, ACC, true>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
@@ -2362,10 +2508,12 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
             hipLaunchKernelGGL(k2_rows_h16, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st,
                                reinterpret_cast<unsigned*>(work), reinterpret_cast<const unsigned*>(hc), reinterpret_cast<unsigned*>(dst),
                                pl, (unsigned)npairs, pre);
-        } else if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
+        } else if (half && AM_K2_PLANES) hipLaunchKernelGGL(k2_rows_r16_planes<true>, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st, work, hc,
+                                                          dst, pl, (unsigned)npairs, hscale);
+        else if (half) hipLaunchKernelGGL((k2_rows_r16<false, true>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                      dst, pl, (unsigned)npairs, hscale);
-        else if (AM_K2_PLANES) hipLaunchKernelGGL(k2_rows_r16_planes, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st, work, hc,
-                                                  dst, pl, (unsigned)npairs);
+        else if (AM_K2_PLANES) hipLaunchKernelGGL(k2_rows_r16_planes<false>, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st, work, hc,
+                                                  dst, pl, (unsigned)npairs, 1.0f);
         else hipLaunchKernelGGL((k2_rows_r16<false, false>), dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, hc,
                                 dst, pl, (unsigned)npairs, 1.0f);
     } else {
@@ -2379,8 +2527,10 @@ bool plan_k2_has_group(const PlanDev& pl) { return plan_k2_is_r16(pl); }
 
 hipError_t launch_k2_group(hipStream_t st, int npairs, const float2* work, const K2Group& grp, const PlanDev& pl) {
     if (!plan_k2_has_group(pl) || grp.n < 1 || grp.n > kMaxNeedleGroup) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k2_rows_r16_group, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, grp, pl,
-                       (unsigned)npairs);
+    if (AM_K2G_PLANES) hipLaunchKernelGGL(k2_rows_r16_group_planes, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st, work, grp, pl,
+                                          (unsigned)npairs);
+    else hipLaunchKernelGGL(k2_rows_r16_group, dim3((unsigned)npairs << pl.logN1), dim3(256), kR16Lds, st, work, grp, pl,
+                            (unsigned)npairs);
     return hipGetLastError();
 }
 

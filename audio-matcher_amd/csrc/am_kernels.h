@@ -33,6 +33,14 @@ struct PlanDev {
     const float2* tw2;    // W_N2^k, k < N2/2
     const float2* twlo;   // W_N^m,            m < 2^logLo
     const float2* twhi;   // W_N^(m << logLo), m < 2^(logN - logLo)
+    // The same two tables with every entry's FOURTH power beside it, (w.x, w.y, w^4.x, w^4.y): one 16-byte
+    // fetch per level yields W_N^m and W_N^(4m), the two seeds of a twiddle chain (twiddle_chain(x, base, step, step4)).
+    const float4* twlo4;
+    const float4* twhi4;
+    // K2's twiddle seeds per lane, ready to fetch (N2 = 8192 only): k2j[2t] = (W^(2t), W^(2t+1)), k2j[2t+1] = their
+    // fourth powers, t < 256; k2c[2c] = (W^(32c), W^(32c+16)), k2c[2c+1] = their fourth powers, c < 16 (W = W_8192).
+    const float4* k2j;
+    const float4* k2c;
 };
 
 constexpr int kColsLog = 5;            // B = 32 columns per K1/K3 workgroup
