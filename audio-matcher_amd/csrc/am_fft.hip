@@ -1260,16 +1260,18 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // minimum of each 16-lane row in its last lane, row_bcast:15 / :31 carry it across the rows into
 // lane 63, which is read back as a scalar.  A lane without a source keeps its own value (`old`).
 __device__ __forceinline__ float wave_min_f(float v) {
-    auto step = [](float x, auto ctrl, auto row_mask) {
-        const int y = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
-        return fminf(x, __int_as_float(y));
-    };
-    v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
-    v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
-    v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
-    v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8
-    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
-    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+    // v_min_f32 with a DPP source: one instruction per step (through the builtin the compiler emits a copy, the DPP
+    // move, a canonicalising max and the min).  dst = src1 = v, so a lane without a source (its write is
+    // suppressed) keeps its value.  s_nop 1: the two wait states between a VALU write of a register and a DPP
+    // read of it, which nobody inserts inside an asm block.
+    asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -1372,6 +1374,12 @@ __device__ __forceinline__ K3Edges k3_edges(const Job& job, const ScanCfg& scan,
     e.outA = blkA * job.hop; e.outB = blkB * job.hop;
     e.one_edge = scan.stats32 != nullptr && scan.seg_c >= (long long)job.hop + 32;
     e.relcA = e.reldA = e.relcB = e.reldB = 0x7fffffff;
+    if (scan.edges_n > 0) {   // from the host (a scalar fetch out of the kernel arguments instead of f64 arithmetic in every wave)
+        const int s = (int)(blkA >> 1) - job.first_pair;
+        e.relcA = scan.edge_rel[s][0]; e.reldA = scan.edge_rel[s][1];
+        e.relcB = scan.edge_rel[s][2]; e.reldB = scan.edge_rel[s][3];
+        return e;
+    }
     if (e.one_edge) {
         const long long c = scan.seg_c, d = scan.seg_d;
         const long long m = mod_recip(e.outA, c, scan.inv_c);
@@ -2547,9 +2555,33 @@ hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, cons
 }
 
 // scan.stats32 != nullptr only for the plans with a fused scan (plan_has_scan) and a 1024-aligned hop
+// the chunk edges of the launch's block pairs (ScanCfg::edge_rel; mirrors k3_edges)
+static void fill_edges(const Job& job, int npairs, ScanCfg& scan) {
+    scan.edges_n = 0;
+    const long long c = scan.seg_c, d = scan.seg_d, hop = job.hop;
+    if (scan.stats32 == nullptr || npairs > ScanCfg::kMaxEdgeSlots || c < hop + 32) return;
+    auto rel = [](long long edge, long long start) { const long long r = edge - start; return r < 0x7fffffffll ? (int)r : 0x7fffffff; };
+    for (int s = 0; s < npairs; ++s) {
+        const long long outA = 2ll * (job.first_pair + s) * hop, outB = outA + hop;
+        const long long m = outA % c;
+        const long long ecA = m == 0 ? outA : outA + (c - m);   // smallest i*c >= outA
+        long long edA = d;                                      // smallest i*c + d >= outA, i >= 0
+        if (outA > d) {
+            const long long m2 = (outA - d) % c;
+            edA = m2 == 0 ? outA : outA + (c - m2);
+        }
+        const long long ecB = ecA >= outB ? ecA : ecA + c, edB = edA >= outB ? edA : edA + c;
+        scan.edge_rel[s][0] = rel(ecA, outA); scan.edge_rel[s][1] = rel(edA, outA);
+        scan.edge_rel[s][2] = rel(ecB, outB); scan.edge_rel[s][3] = rel(edB, outB);
+    }
+    scan.edges_n = npairs;
+}
+
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
-                     const PlanDev& pl, float out_scale, const ScanCfg& scan, int half, bool accumulate) {
+                     const PlanDev& pl, float out_scale, const ScanCfg& scan_in, int half, bool accumulate) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
+    ScanCfg scan = scan_in;
+    fill_edges(job, npairs, scan);
     if (scan.only_pairs != nullptr && !accumulate && plan_has_scan(pl)) {
         // the device-side redo: the same kernels under names of their own
         const dim3 g1((unsigned)npairs * (kN2 >> kColsLog));
