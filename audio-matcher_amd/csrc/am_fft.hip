@@ -349,6 +349,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 #ifndef AM_K3_LOAD_NT
 #define AM_K3_LOAD_NT 1   // K3's once-read column loads: 0.180 -> 0.156 ms per 1 h haystack (profiles/r02/nt_ab.txt)
 #endif
+#ifndef AM_K3H_LOAD_AUX
+#define AM_K3H_LOAD_AUX 2   // K3's column loads from a half-storage work matrix: nt, as the f32 form's
+#endif
 #ifndef AM_K1_LOAD_NT
 #define AM_K1_LOAD_NT 1   // K1's sample loads: 0.269 -> 0.261 ms with the 512-row kernel (profiles/r02/nt_ab_c512.txt)
 #endif
@@ -400,8 +403,9 @@ __device__ __forceinline__ unsigned pack_h2(float2 v) {
 __device__ __forceinline__ float2 unpack_h2(unsigned u) {
     return __half22float2(__builtin_bit_cast(__half2, u));
 }
+template <int AUX = 0>
 __device__ __forceinline__ uint2 buf_load_u2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
     // element-wise through scalars: __builtin_bit_cast on a vector ELEMENT reads the
     // vector's first lane for every element (observed with ROCm 7.2's clang)
     const float lo = v.x, hi = v.y;
@@ -979,7 +983,7 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
 #define AM_K2_PLANES 1
 #endif
 #ifndef AM_K2P_WAVES
-#define AM_K2P_WAVES 3
+#define AM_K2P_WAVES 4   // (both forms fit 124 registers: four workgroups per CU, 136 KB of LDS)
 #endif
 // row load, forward passes 1 and 2 and the exchange into pass 3's layout: z[r] = point r of the thread's row u = t
 template <bool HALF>
@@ -1874,11 +1878,14 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
         // first pass (pipeline twiddle, 16-point transform over beta, the W_32 branch factors) and the
         // exchange on packed half-precision points, both columns in one exchange; the second pass and
         // everything behind it in f32, so that no score is rounded to f16 on the way out
-        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
+        // (buffer loads: one address register for all 16, see the f32 form below)
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0,
+                                                     (unsigned)((N - n2_0) * 4));
+        const unsigned voff = (unsigned)k10 * (kN2 * 4u) + (unsigned)cp * 8u;
         h2 hx0[16], hx1[16];
 #pragma unroll
         for (int bt = 0; bt < 16; ++bt) {
-            const uint2 v = in2[(size_t)(k10 + 32 * bt) * (kN2 / 2)];
+            const uint2 v = buf_load_u2<AM_K3H_LOAD_AUX>(rin, voff, (unsigned)bt * (32u * kN2 * 4u));
             hx0[bt] = bits_h2(v.x);
             hx1[bt] = bits_h2(v.y);
         }
@@ -1922,10 +1929,12 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
         return;
     }
     if (HALF) {
-        const uint2* __restrict__ in2 = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0) + cp;
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(reinterpret_cast<const unsigned*>(work) + ((size_t)slot << pl.logN) + n2_0,
+                                                     (unsigned)((N - n2_0) * 4));
+        const unsigned voff = (unsigned)k10 * (kN2 * 4u) + (unsigned)cp * 8u;
 #pragma unroll
         for (int bt = 0; bt < 16; ++bt) {
-            const uint2 v = in2[(size_t)(k10 + 32 * bt) * (kN2 / 2)];
+            const uint2 v = buf_load_u2<AM_K3H_LOAD_AUX>(rin, voff, (unsigned)bt * (32u * kN2 * 4u));
             const float2 f0 = unpack_h2(v.x), f1 = unpack_h2(v.y);
             x0[bt] = T{f0.x, f0.y};
             x1[bt] = T{f1.x, f1.y};
