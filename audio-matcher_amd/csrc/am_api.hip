@@ -76,9 +76,10 @@ struct Opts {
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
 static const int kLogNMin = 10, kLogNMax = 23;
-// needles longer than this run on N = 2^22 (measured crossover between 4 and 7 s of 44.1 kHz
-// audio, tools/needle_sweep.py, profiles/r02/needle_sweep.txt)
-static const long long kWideFromSamples = 300000;
+// needles longer than this run on N = 2^22 (measured crossover between 2 and 5 s of 44.1 kHz
+// audio, tools/needle_sweep.py, profiles/r03/needle_sweep.txt: 2 s 0.674 against 0.685 ms per hour of
+// audio, 5 s 0.725 against 0.702)
+static const long long kWideFromSamples = 140000;
 // needles longer than this run on N = 2^23 = 1024 x 8192 (measured crossover between 30 and 36 s of 44.1 kHz
 // audio, profiles/r03/needle_sweep.txt: the 1024-row column kernels cost more per point, the hop is longer)
 static const long long kWidestFromSamples = 1500000;

@@ -71,7 +71,7 @@ def plan_geometry(s: int, h: int, log_n: int = 0):
     """The library's block layout for a needle of s samples and a haystack of h (am_api.hip pick_log_n /
     plan_geometry): transform length, hop, blocks, pairs."""
     if not log_n:
-        log_n = 21 if s <= 300000 else 22
+        log_n = 21 if s <= 140000 else 22
         hop21 = (2 ** 21 - s + 1) // 1024 * 1024
         if log_n == 22 and 0 < h - s + 1 <= 2 * hop21:     # a short haystack: one pair of 2^21 blocks is enough
             log_n = 21
