@@ -23,7 +23,7 @@ done
 python3 - "$out" <<'PY'
 import collections, csv, glob, json, sys
 root = sys.argv[1]
-KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": "k2_rows_r16<false", "k3_cols_inv": "k3_cols_inv_"}
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": "k2_rows_r16_planes", "k3_cols_inv": "k3_cols_inv_"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/pass*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

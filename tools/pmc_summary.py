@@ -15,7 +15,7 @@ import glob
 import json
 import sys
 
-KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16<false", "k2_rows_h16"), "k3_cols_inv": "k3_cols_inv_",
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16<false", "k2_rows_r16_planes", "k2_rows_h16"), "k3_cols_inv": "k3_cols_inv_",
         "tile_stats": "stats_reduce", "peaks": "peaks_kernel",
         "k2_rows_group": "k2_rows_r16_group"}   # (peaks_wide / peaks_finish return at once on this workload)
 

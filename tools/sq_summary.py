@@ -8,7 +8,7 @@ import glob
 import json
 import sys
 
-KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": "k2_rows_r16<false", "k2_rows_h16": "k2_rows_h16", "k3_cols_inv": "k3_cols_inv_",
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16<false", "k2_rows_r16_planes"), "k2_rows_h16": "k2_rows_h16", "k3_cols_inv": "k3_cols_inv_",
         "k2_rows_group": "k2_rows_r16_group"}
 
 
@@ -22,7 +22,8 @@ def main():
     for key, pat in KEYS.items():
         agg = {}
         for name, counters in vals.items():
-            if pat not in name or name.split("(")[0].rstrip().endswith(", 1>"):   # (skip the device-side redo's K3 instantiations)
+            pats = (pat,) if isinstance(pat, str) else pat
+            if not any(p_ in name for p_ in pats) or name.split("(")[0].rstrip().endswith(", 1>"):   # (skip the device-side redo's K3 instantiations)
                 continue
             for cname, lst in counters.items():
                 gmax = max(g for _, g in lst)
@@ -38,6 +39,9 @@ def main():
             "frac_wave_cycles_waiting_for_issue": agg.get("SQ_WAIT_INST_ANY", 0) / wc,
             "frac_wave_cycles_issuing": agg.get("SQ_ACTIVE_INST_ANY", 0) / wc,
             "valu_insts_per_wave": agg.get("SQ_INSTS_VALU", 0) / w,
+            # share of the kernel's cycles in which a SIMD's VALU is busy if every VALU instruction takes four
+            # cycles (1024 SIMDs; SQ_BUSY_CYCLES is summed over the chip's 32 shader engines)
+            "valu_busy_at_4_cycles": agg.get("SQ_INSTS_VALU", 0) * 4.0 / (max(agg.get("SQ_BUSY_CYCLES", 0), 1) / 32.0 * 1024.0),
             "lds_insts_per_wave": agg.get("SQ_INSTS_LDS", 0) / w,
             "vmem_insts_per_wave": (agg.get("SQ_INSTS_VMEM_RD", 0) + agg.get("SQ_INSTS_VMEM_WR", 0)) / w,
             "lds_bank_conflict_share_of_lds_active": agg.get("SQ_LDS_BANK_CONFLICT", 0) / (agg.get("SQ_LDS_IDX_ACTIVE", 0) or 1),
