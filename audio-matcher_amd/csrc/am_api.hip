@@ -69,9 +69,10 @@ static std::atomic<long long> g_opt_profile_mask{-1};    // bit i = bracket kern
 static std::atomic<long long> g_opt_half{0};             // 1 = half-precision storage of the work matrix (config 5)
 static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
 static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
+static std::atomic<long long> g_opt_device_redo{1};      // 0 = failed certificates are redone by the host path only (experiments)
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
 struct Opts {
-    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense;
+    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo;
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
@@ -336,6 +337,11 @@ struct am_needle {
     // device, it takes the median -- the background level -- so that a few chunks with deep dips (a hit whose
     // autocorrelation has negative lobes) do not make every later haystack write all its scores
     int conservative_left[2] = {0, 0};
+    // haystacks left for which a batch queues the device-side redo (a K3 launch that looks at the pairs' flags and
+    // a second pick per haystack: 1.6 % of the headline's time when nothing ever fails).  Armed by a failed
+    // certificate -- of an earlier call, or of an earlier haystack of the same call as soon as its flag has
+    // arrived in host memory; until then such a chunk is redone from the host, as in single calls.
+    int redo_armed_left[2] = {0, 0};
     float hist_min(int sm) const {
         float m = FLT_MAX;
         for (int i = 0; i < recent_n[sm]; ++i) m = std::min(m, recent_min[sm][i]);
@@ -360,6 +366,7 @@ static Opts snapshot_opts(const am_needle* h) {
     o.batch_overlap = g_opt_batch_overlap.load(std::memory_order_relaxed);
     o.needle_group = g_opt_needle_group.load(std::memory_order_relaxed);
     o.dense = g_opt_dense.load(std::memory_order_relaxed);
+    o.device_redo = g_opt_device_redo.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -1075,7 +1082,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // the pick marks the block pairs that feed it, K3 runs once more for those pairs with every run written
     // (from the haystack's own work matrix: two alternate) and the chunk is picked again -- all on the
     // second stream, no host round trip.  (Single calls redo such a chunk from the host, below.)
-    const bool device_redo = overlap && sparse_ok && !needle_is_segmented(h, o);
+    const bool device_redo = overlap && sparse_ok && !needle_is_segmented(h, o) && o.device_redo != 0;
     if (device_redo) {   // sized once for the haystack with the most block pairs: no pick of the batch waits for an allocation
         long long most = 1;
         for (size_t k = 0; k < n_hay; ++k) {
@@ -1092,9 +1099,15 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                 hooks.chunk_fn(hooks.chunk_user, G(k), (size_t)i, (size_t)n_chunks[k], stage);
     };
     size_t seq = 0;
+    bool redo_armed = device_redo && h->redo_armed_left[sm] > 0;
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (n_chunks[k] == 0) continue;
+        if (device_redo && !redo_armed && (k & 3) == 0) {
+            // (the flags of the haystacks queued so far: written by their picks, whenever those have run)
+            const volatile unsigned char* f = h_fail;
+            for (int i = 0; i < seg_off[k] && !redo_armed; ++i) redo_armed = f[i] != 0;
+        }
         if (hooks.fn) hooks.fn(hooks.user, G(k), 0, (size_t)n_chunks[k]);
         chunk_events(k, 0);
         if (ns == 0) continue;
@@ -1107,7 +1120,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         scan.before_k3 = nullptr;
         scan.work_by_set = overlap;
         int* d_redo = nullptr;
-        if (device_redo) {
+        if (redo_armed) {
             Geometry g{};
             if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
             if ((rc = c->redo_pairs[set].ensure(sizeof(int) * (size_t)g.npairs))) return rc;
@@ -1135,7 +1148,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         }
         if (scan.fused && scan.sparse.wbits) {
             scan.sparse.fail_flags = h_fail + seg_off[k];
-            scan.sparse.redo_pairs = (device_redo && scan.redo_ok) ? d_redo : nullptr;
+            scan.sparse.redo_pairs = (redo_armed && scan.redo_ok) ? d_redo : nullptr;
         }
         if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence,
                               (long long)p->min_distance, &scan, seg_off[k], arena, overlap ? c->stream2 : c->stream))) return rc;
@@ -1184,6 +1197,8 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             const bool robust = device_redo && h->conservative_left[sm] == 0;
             h->remember_min(sm, robust ? mins[mins.size() / 2] : mins.front());
             if (h->conservative_left[sm] > 0) --h->conservative_left[sm];
+            if (failed) h->redo_armed_left[sm] = 64;
+            else if (h->redo_armed_left[sm] > 0) --h->redo_armed_left[sm];
         }
         all.clear();
         // Non-finite samples (NaN, +-inf; f32 sources only).  The reference transforms every window
@@ -2501,6 +2516,7 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
         if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
         g_opt_needle_group = value; return AM_OK;
@@ -2520,6 +2536,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
+    if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }

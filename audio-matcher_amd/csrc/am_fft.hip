@@ -1641,18 +1641,16 @@ __device__ __forceinline__ void k3_tile_h16(const Job& job, const PlanDev& pl, c
 #ifndef AM_K3_WGS
 #define AM_K3_WGS 3   // waves per SIMD the register allocation has to allow (= workgroups per CU for 256 threads; it uses 118 VGPRs: four fit)
 #endif
-// REDO only names the instantiation that the device-side redo launches (the same code: scan.only_pairs picks the
-// pairs), so that a kernel trace lists those all-but-empty launches apart from the pipeline's K3
-template <int HALF, bool ACC = false, int REDO = 0>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
-__global__ void __launch_bounds__(256, AM_K3_WGS)
-k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
-    extern __shared__ float4 lds4[];
+// One column tile of the 256-row K3; lin = the tile's number in the launch (blockIdx.x in the pipeline's launches).
+template <int HALF, bool ACC>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
+__device__ __forceinline__ void k3_cols_inv_r16_tile(unsigned lin, float4* lds4, const Job& job, const float2* __restrict__ work,
+                                                     const PlanDev& pl, float out_scale, const ScanCfg& scan) {
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     // XCD-aware placement (speed only): the 16 adjacent column tiles that share
     // one 128-byte line of stats32 run on the same XCD, so the line is merged in
     // that L2 before it is written back.  256 tiles per pair = 8 XCDs x 2 x 16.
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned xcd = lin & 7u, seq = lin >> 3;
     const unsigned slot = seq >> 5, half = (seq >> 4) & 1u, tl = seq & 15u;
     const int n2_0 = (int)(((half * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
@@ -1689,6 +1687,23 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
         }
     }
     k3_tile<ACC>(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+}
+// The kernel: one tile per workgroup.  REDO = the device-side redo's instantiation (a name of its own in kernel
+// traces): a SMALL grid walks the launch's tiles and runs those of the flagged pairs (scan.only_pairs) -- most
+// launches of it find nothing to do, and 512 workgroups that look at 22 flags are gone sooner than 5632 that each
+// need a workgroup's worth of LDS and registers to find out.
+template <int HALF, bool ACC = false, int REDO = 0>
+__global__ void __launch_bounds__(256, REDO ? 4 : AM_K3_WGS)
+k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    if constexpr (REDO != 0) {
+        for (unsigned lin = blockIdx.x; lin < (unsigned)scan.redo_tiles; lin += gridDim.x) {
+            k3_cols_inv_r16_tile<HALF, ACC>(lin, lds4, job, work, pl, out_scale, scan);
+            __syncthreads();   // the next tile's exchanges overwrite the scan rows other wavefronts may still read
+        }
+    } else {
+        k3_cols_inv_r16_tile<HALF, ACC>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
+    }
 }
 
 // ===========================================================================
@@ -1849,17 +1864,16 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <int HALF, bool ACC = false, int REDO = 0>   // as in k1_cols_fwd_c512
-__global__ void __launch_bounds__(512, 2)   // (uses 119 / 117 VGPRs: two workgroups per CU; a tighter bound makes the allocator spill)
-k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
-    extern __shared__ float4 lds4[];
+template <int HALF, bool ACC>   // as in k1_cols_fwd_c512
+__device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4, const Job& job, const float2* __restrict__ work,
+                                                      const PlanDev& pl, float out_scale, const ScanCfg& scan) {
     float2* lds2 = reinterpret_cast<float2*>(lds4);
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const int ap = hi & 15, half = hi >> 4;
     const int k10 = ap + 16 * half;
     // placement as in k3_cols_inv_r16: the 16 column tiles that share a line of the summary on one XCD
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned xcd = lin & 7u, seq = lin >> 3;
     const unsigned slot = seq >> 5, hf = (seq >> 4) & 1u, tl = seq & 15u;
     const int n2_0 = (int)(((hf * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
@@ -2001,6 +2015,19 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     dif<16, true>(x1);
     k3_finish<5, T, ACC, true>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
+template <int HALF, bool ACC = false, int REDO = 0>   // (REDO: see k3_cols_inv_r16)
+__global__ void __launch_bounds__(512, REDO ? 4 : 2)   // (113 - 119 VGPRs, two workgroups per CU, without being told; the loop of the REDO form has to be held to 128)
+k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    if constexpr (REDO != 0) {
+        for (unsigned lin = blockIdx.x; lin < (unsigned)scan.redo_tiles; lin += gridDim.x) {
+            k3_cols_inv_c512_tile<HALF, ACC>(lin, lds4, job, work, pl, out_scale, scan);
+            __syncthreads();
+        }
+    } else {
+        k3_cols_inv_c512_tile<HALF, ACC>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
+    }
+}
 
 // ===========================================================================
 // N = 2^23 = 1024 x 8192: column kernels with 1024 threads (one workgroup = 16 waves per CU, the
@@ -2125,17 +2152,16 @@ k1_cols_fwd_c1024(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <bool ACC, int REDO = 0>   // ACC: add to what job.dst holds (needle partitioning, see k3_finish)
-__global__ void __launch_bounds__(1024)
-k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
-    extern __shared__ float4 lds4[];
+template <bool ACC>   // ACC: add to what job.dst holds (needle partitioning, see k3_finish)
+__device__ __forceinline__ void k3_cols_inv_c1024_tile(unsigned lin, float4* lds4, const Job& job, const float2* __restrict__ work,
+                                                       const PlanDev& pl, float out_scale, const ScanCfg& scan) {
     float2* lds2 = reinterpret_cast<float2*>(lds4);
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const int ap = hi & 15, q = hi >> 4;
     const int k10 = ap + 16 * q;
     // placement as in k3_cols_inv_r16: the 16 column tiles that share a line of the summary on one XCD
-    const unsigned lin = blockIdx.x, xcd = lin & 7u, seq = lin >> 3;
+    const unsigned xcd = lin & 7u, seq = lin >> 3;
     const unsigned slot = seq >> 5, hf = (seq >> 4) & 1u, tl = seq & 15u;
     const int n2_0 = (int)(((hf * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
@@ -2194,6 +2220,19 @@ k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float ou
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*64 + b
     dif<16, true>(x1);
     k3_finish<6, float2, ACC>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+}
+template <bool ACC, int REDO = 0>   // (REDO: see k3_cols_inv_r16)
+__global__ void __launch_bounds__(1024)
+k3_cols_inv_c1024(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    if constexpr (REDO != 0) {
+        for (unsigned lin = blockIdx.x; lin < (unsigned)scan.redo_tiles; lin += gridDim.x) {
+            k3_cols_inv_c1024_tile<ACC>(lin, lds4, job, work, pl, out_scale, scan);
+            __syncthreads();
+        }
+    } else {
+        k3_cols_inv_c1024_tile<ACC>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
+    }
 }
 
 // ===========================================================================
@@ -2593,7 +2632,10 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
     fill_edges(job, npairs, scan);
     if (scan.only_pairs != nullptr && !accumulate && plan_has_scan(pl)) {
         // the device-side redo: the same kernels under names of their own
-        const dim3 g1((unsigned)npairs * (kN2 >> kColsLog));
+        // (a grid of one round of resident workgroups -- 1, 2, 4 per CU -- walks the tiles)
+        scan.redo_tiles = npairs * (kN2 >> kColsLog);
+        const unsigned per_cu = plan_is_c1024(pl) ? 1u : plan_is_c512(pl) ? 2u : 4u;
+        const dim3 g1(std::min<unsigned>((unsigned)scan.redo_tiles, 256u * per_cu));
         if (plan_is_c1024(pl)) {
             if (half) return hipErrorInvalidValue;
             hipLaunchKernelGGL((k3_cols_inv_c1024<false, 1>), g1, dim3(1024), kC1024Lds, st, job, work, pl, out_scale, scan);

@@ -89,6 +89,7 @@ struct ScanCfg {
     // marks the pairs of the chunks whose certificate failed (SparseScores::redo_pairs), K3 then runs once
     // more for those pairs with every run written, from the work matrix it still has.
     const int* only_pairs;
+    int redo_tiles;           // (set by launch_k3 for that launch: tiles in the launch, walked by a small grid)
     // Chunk edges per block pair of the launch, worked out on the host (launch_k3): for slot s of the launch the first
     // score i*seg_c and the first score i*seg_c + seg_d at or behind the start of block A (0, 1) and of block B (2, 3),
     // relative to that start, INT_MAX when out of reach.  edges_n = 0 (more pairs than kMaxEdgeSlots, or chunks

@@ -325,7 +325,10 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *       stays inside f16's range, inputs far above full scale may overflow it.
  *   "dense_scores" (0/1): write every raw score from the inverse pass (threshold -inf)
  *       instead of only the tiles that can matter to the peak pick; results are
- *       identical, this is the worst case of the sparse-score path for measurements. */
+ *       identical, this is the worst case of the sparse-score path for measurements.
+ *   "device_redo" (0/1, default 1): in a batch, chunks whose sparse-score certificate fails get their dense
+ *       inverse pass on the device, beside the next haystack's transforms; 0 = the host path does it
+ *       after the call's kernels (results are identical; for measurements). */
 int am_set_option(const char* key, long long value);
 int am_get_option(const char* key, long long* value);
 /* "log_n" and "half_pipeline" per needle handle: -1 = follow the process default (initial
