@@ -434,6 +434,16 @@ __device__ __forceinline__ float load_sample(const void* __restrict__ src, long 
     if (KIND == 0) return static_cast<const float*>(src)[i];
     return downmix_s16(static_cast<const short2*>(src)[i]);
 }
+// two consecutive samples out of the 8 bytes a 64-bit load returned (an f32 sample and an i16 stereo frame
+// are both 4 bytes)
+template <int KIND>
+__device__ __forceinline__ float2 decode_sample2(uint2 raw) {
+    if (KIND == 0) return make_float2(__uint_as_float(raw.x), __uint_as_float(raw.y));
+    short2 a, b;
+    a.x = (short)(raw.x & 0xffffu); a.y = (short)(raw.x >> 16);
+    b.x = (short)(raw.y & 0xffffu); b.y = (short)(raw.y >> 16);
+    return make_float2(downmix_s16(a), downmix_s16(b));
+}
 // two consecutive samples from an 8-byte aligned position
 template <int KIND>
 __device__ __forceinline__ float2 load_sample2(const void* __restrict__ src, long long i) {
@@ -1764,7 +1774,22 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
         step1 = tw_big(pl, (((unsigned)col + 1u) * 32u) & maskN);
     }
     float2 x0[16], x1[16];
-    if (fast) {
+    if (fast && KIND == 1) {
+        // i16 stereo: buffer loads off one address register -- row a's offset (a MB) and block B's (hop frames) ride
+        // in SGPRs, so the 32 requests leave back to back instead of behind a 64-bit address addition each.  K1 with
+        // the down-mix and the f16 butterflies 0.255 -> 0.246 ms; the f32 form, which waits on memory either way,
+        // measures the same with both kinds of load and keeps the plain ones below
+        // (profiles/r03/k2_planes_k3_diet_ab.txt).
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(static_cast<const char*>(job.src) + 4 * baseA, (unsigned)(4 * (N + job.hop)));
+        const unsigned voff = 4u * ((unsigned)hi * kN2 + (unsigned)col), offB = 4u * (unsigned)job.hop;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const float2 va = decode_sample2<KIND>(buf_load_u2<AM_K1_LOAD_NT ? 2 : 0>(rsrc, voff, (unsigned)a * (4u * 32u * kN2)));
+            const float2 vb = decode_sample2<KIND>(buf_load_u2<AM_K1_LOAD_NT ? 2 : 0>(rsrc, voff, (unsigned)a * (4u * 32u * kN2) + offB));
+            x0[a] = make_float2(va.x, vb.x);
+            x1[a] = make_float2(va.y, vb.y);
+        }
+    } else if (fast) {
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             const long long off = (long long)(a * 32 + hi) * kN2 + col;
