@@ -1579,6 +1579,8 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
         const unsigned n2 = (unsigned)col;
         float2 base0 = tw_big(pl, (n2 * (unsigned)hi) & maskN);
         float2 base1 = tw_big(pl, ((n2 + 1) * (unsigned)hi) & maskN);
+        base0.x *= out_scale; base0.y *= out_scale;   // (out_scale rides on the pipeline twiddle, as in the 512-row kernel)
+        base1.x *= out_scale; base1.y *= out_scale;
         float2 step0, step1, step0q, step1q;
         tw_big_pair(pl, (n2 * 16u) & maskN, step0, step0q);
         tw_big_pair(pl, ((n2 + 1) * 16u) & maskN, step1, step1q);
@@ -1604,7 +1606,7 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
     twiddle_nat<16, true>(x1, w256, w256q);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
-    k3_finish<4, float2, ACC>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
+    k3_finish<4, float2, ACC, true>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
 }
 
 // The same with the first pass (pipeline twiddle, 16-point transform over b') and the exchange on
@@ -1688,10 +1690,12 @@ __device__ __forceinline__ void k3_cols_inv_r16_tile(unsigned lin, float4* lds4,
             x1[bp] = unpack_h2(v.y);
         }
     } else {
-        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+        // (buffer loads off one address register, as in the 512-row kernel)
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(work + ((size_t)slot << pl.logN) + n2_0, (unsigned)((((size_t)1 << pl.logN) - n2_0) * 8));
+        const unsigned voff = (unsigned)hi * (kN2 * 8u) + (unsigned)cp * 16u;
 #pragma unroll
         for (int bp = 0; bp < 16; ++bp) {   // rows k1 = a' + 16*b', a' = hi
-            const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(hi + 16 * bp) * (kN2 / 2));
+            const float4 v = buf_load4<AM_K3_LOAD_NT ? 2 : 0>(rin, voff, (unsigned)bp * (16u * kN2 * 8u));
             x0[bp] = make_float2(v.x, v.y);
             x1[bp] = make_float2(v.z, v.w);
         }
@@ -2196,11 +2200,12 @@ __device__ __forceinline__ void k3_cols_inv_c1024_tile(unsigned lin, float4* lds
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned n2 = (unsigned)n2_0 + 2u * (unsigned)cp;
     float2 x0[16], x1[16];
-    {
-        const float4* __restrict__ in4 = reinterpret_cast<const float4*>(work + ((size_t)slot << pl.logN) + n2_0) + cp;
+    {   // (buffer loads off one address register, as in the 512-row kernel)
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(work + ((size_t)slot << pl.logN) + n2_0, (unsigned)((N - n2_0) * 8));
+        const unsigned voff = (unsigned)k10 * (kN2 * 8u) + (unsigned)cp * 16u;
 #pragma unroll
         for (int bt = 0; bt < 16; ++bt) {   // rows k1 = k10 + 64*beta
-            const float4 v = load_f4<AM_K3_LOAD_NT>(in4 + (size_t)(k10 + 64 * bt) * (kN2 / 2));
+            const float4 v = buf_load4<AM_K3_LOAD_NT ? 2 : 0>(rin, voff, (unsigned)bt * (64u * kN2 * 8u));
             x0[bt] = make_float2(v.x, v.y);
             x1[bt] = make_float2(v.z, v.w);
         }
@@ -2209,8 +2214,10 @@ __device__ __forceinline__ void k3_cols_inv_c1024_tile(unsigned lin, float4* lds
     const float2 w1024 = pl.tw1[hi];
     const float2 w64q = pl.tw1[16 * q];
     {
-        const float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
-        const float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
+        float2 base0 = tw_big(pl, (n2 * (unsigned)k10) & maskN);
+        float2 base1 = tw_big(pl, ((n2 + 1u) * (unsigned)k10) & maskN);
+        base0.x *= out_scale; base0.y *= out_scale;   // (out_scale rides on the pipeline twiddle, as in the 512-row kernel)
+        base1.x *= out_scale; base1.y *= out_scale;
         const float2 step0 = tw_big(pl, (n2 * 64u) & maskN);
         const float2 step1 = tw_big(pl, ((n2 + 1u) * 64u) & maskN);
         twiddle_chain<16, true, false>(x0, base0, step0);
@@ -2244,7 +2251,7 @@ __device__ __forceinline__ void k3_cols_inv_c1024_tile(unsigned lin, float4* lds
     twiddle_nat<16, true>(x1, w1024);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*64 + b
     dif<16, true>(x1);
-    k3_finish<6, float2, ACC>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_finish<6, float2, ACC, true>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 template <bool ACC, int REDO = 0>   // (REDO: see k3_cols_inv_r16)
 __global__ void __launch_bounds__(1024)
