@@ -23,16 +23,19 @@
 //                    -> scores of block 2g+1, plus a (min,max) summary per 32
 //                    scores for the peak pick.
 //
-// Three families of kernels exist:
-//   *_c512: K1/K3 for N = 2^22 = 512 x 8192 (needles above ~7 s): 512-thread column
-//           kernels, 512-point column transform as 16 x 32.
-//   *_r16 : the production shape N1 = 256, N2 = 8192 (N = 2^21).  Radix-16/32
-//           butterflies held in VGPRs, LDS used only for the exchanges between
-//           passes (conflict-free 16-byte accesses, XOR-swizzled rows), 16-byte
-//           coalesced HBM accesses, twiddles by binary powering of one table
-//           entry.
-//   *_gen : any N = 2^10 .. 2^23 (small inputs, unusual needle lengths):
-//           in-LDS radix-4 passes.
+// Four families of kernels exist (all with N2 = 8192-point rows except *_gen):
+//   *_c512 : K1/K3 for N = 2^22 = 512 x 8192 (needles from 3.2 s up, the headline): 512-thread column
+//            kernels, 512-point column transform as 16 x 32.
+//   *_r16  : N1 = 256 (N = 2^21; short needles).  Radix-16/32 butterflies held in VGPRs, LDS used
+//            only for the exchanges between passes (conflict-free accesses, XOR-swizzled rows), 16-byte
+//            coalesced HBM accesses.
+//   *_c1024: K1/K3 for N = 2^23 = 1024 x 8192 (needles above 34 s; needle partitioning above 2^22 samples).
+//   *_gen  : any N = 2^10 .. 2^23 (small inputs, forced plans): in-LDS radix-4 passes.
+// K2 of the register plans is k2_rows_r16_planes (the row crosses LDS one 32 KB plane at a time: four
+// workgroups per CU -- the row kernel is bound by VALU issue), k2_rows_r16_group_planes
+// for several needles, k2_rows_h16 with packed-f16 butterflies.  Twiddle powers come from TWO table entries
+// per pass boundary (w and w^4, twiddle_apply / twiddle_chain below): a power e of one rounded entry carries
+// e times its rounding error.
 // The needle spectrum is produced by the same K1/K2 code of the same flavour
 // and therefore always lives in the layout the multiply expects.
 #include "am_kernels.h"
