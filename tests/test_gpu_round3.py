@@ -637,6 +637,13 @@ def test_failed_certificates_in_a_batch_are_redone_on_the_device(gpu, oracle):
     assert [key(r) for r in res] == want[::-1]
     for r, e in zip(res[::-1], exps):
         assert_same(r, e)
+    # a long batch through a FRESH handle: nothing is armed when the call starts, the first failures take the host
+    # path, and the redo may get armed while the call is still queuing (whenever a flag has reached host memory by
+    # then) -- whichever haystack takes which path, the results are the single calls'
+    fresh = gpu.HipConvolve(needle)
+    order = [0, 2, 1, 3] * 4
+    res = fresh.match_batch_device([ptrs[i] for i in order], [lens[i] for i in order], p)
+    assert [key(r) for r in res] == [want[i] for i in order]
     # i16 input and the half-precision levels go the same way
     pool = gpu.Pool(needle, [0, 0])
     assert [key(r) for r in pool.match_batch_device(ptrs, lens, p)] == want
