@@ -1053,14 +1053,29 @@ __device__ __forceinline__ void k2p_forward(const K2Lane& k, __amdgpu_buffer_rsr
 }
 
 // inverse passes 3, 2, 1 of the product q and the row store
-template <bool HALF, int SAUX = AM_K2_STORE_AUX>
+// LATE_J: the first boundary's seeds are fetched behind pass 2, where they are wanted, instead of with the second
+// boundary's at the start: the needle-group kernel, which carries the forward spectrum through this function, gets
+// from 12 spilled registers to 5 with it (1.46 -> 1.37 ms per launch); the single-needle kernel has the registers
+// and measures 2 % slower with the later fetch.
+template <bool HALF, int SAUX = AM_K2_STORE_AUX, bool LATE_J = false>
 __device__ __forceinline__ void k2p_inverse(const PlanDev& pl, float2 (&q)[32], float2* lds2, __amdgpu_buffer_rsrc_t rdst) {
     // the lane's twiddle seeds are fetched again (L1 / L2 hits, in flight behind pass 3) instead of kept alive
     // across the product: sixteen registers the multiply, the kernel's widest point, does not have
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
-    const K2Lane ki = k2_lane(pl, t);
-    const int hi = ki.hi, cp = ki.cp;
+    const int hi = t >> 4, cp = t & 15;
+    K2Lane ki;
+    ki.t = t; ki.hi = hi; ki.cp = cp; ki.voff = (unsigned)t * 16u;
+    {
+        const float4 c = pl.k2c[2 * cp], cq = pl.k2c[2 * cp + 1];
+        ki.wc0 = make_float2(c.x, c.y); ki.wc1 = make_float2(c.z, c.w);
+        ki.qc0 = make_float2(cq.x, cq.y); ki.qc1 = make_float2(cq.z, cq.w);
+    }
+    if (!LATE_J) {
+        const float4 j = pl.k2j[2 * t], jq = pl.k2j[2 * t + 1];
+        ki.wj0 = make_float2(j.x, j.y); ki.wj1 = make_float2(j.z, j.w);
+        ki.qj0 = make_float2(jq.x, jq.y); ki.qj1 = make_float2(jq.z, jq.w);
+    }
     const K2Lane& k = ki;
     float2 x0[16], x1[16];
     // ---- inverse pass 3 over c' ----
@@ -1083,6 +1098,13 @@ __device__ __forceinline__ void k2p_inverse(const PlanDev& pl, float2 (&q)[32], 
     wave_sync_lds();
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[hi * kK2hSlab + b * 16 + cp] = x0[brev<16>(b)];
+    if (LATE_J) {
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 j = pl.k2j[2 * t], jq = pl.k2j[2 * t + 1];
+        ki.wj0 = make_float2(j.x, j.y); ki.wj1 = make_float2(j.z, j.w);
+        ki.qj0 = make_float2(jq.x, jq.y); ki.qj1 = make_float2(jq.z, jq.w);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     twiddle_nat<16, true>(x1, ki.wc1, ki.qc1);
     dif<16, true>(x1);
     __syncthreads();
@@ -1196,7 +1218,7 @@ k2_rows_r16_group_planes(const float2* __restrict__ work, K2Group grp, PlanDev p
         k2_fetch_quarter(rh, k.voff, 0, hq);
         float2 q[32];
         k2_multiply_fetch(z, rh, k.voff, hq, q);
-        k2p_inverse<false, AM_K2G_STORE_AUX>(pl, q, lds2, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
+        k2p_inverse<false, AM_K2G_STORE_AUX, true>(pl, q, lds2, make_rsrc(grp.dst[j] + row_off, kN2 * 8));
         __syncthreads();   // the last pass read slabs of every wave: finish before the next needle's exchanges overwrite them
     }
 }
