@@ -39,7 +39,14 @@ for g in groups:
             am.match_multi_device(algos, hay.ptr, h, p)
         kern = {n: round(prof.query(n)[0] / 3, 4) for n in KN}
     rate = nn * h / dt
+    # the bytes this design moves per call (bench.py's MultiNeedleWorkload): K1 once (two f32 blocks in, one complex
+    # point out), per group of g needles the rows read once, written g times and g spectra, K3 once per needle
+    npairs, n_fft = 22, 1 << 22
+    pts = npairs * n_fft
+    ngroups = -(-nn // g)
+    design = pts * 16 + (ngroups * pts * 8 + nn * (pts * 8 + n_fft * 8)) + nn * (pts * 8 + (h - s + 1) // 4)
     # (16 + 16 K) N bytes per block of N - S + 1 samples at K = 32, N = 2^22: 18.44 B per needle-sample
     out[f"group{g}"] = {"needles": nn, "needle_samples_per_s": rate, "ms_per_needle_hour": dt / nn * 1e3,
+                        "design_bytes_per_call": design, "design_frac_of_8TBs": design / dt / 8e12,
                         "survey_model_frac_of_8TBs": rate * 18.44 / 8e12, "kernel_ms_per_call": kern}
 print(json.dumps(out, indent=1))
