@@ -1936,6 +1936,9 @@ __device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4
     const long long N = 1ll << pl.logN;
     const unsigned maskN = (unsigned)(N - 1);
     const unsigned n2 = (unsigned)n2_0 + 2u * (unsigned)cp;
+#ifndef AM_K3_INTERLEAVE
+#define AM_K3_INTERLEAVE 1
+#endif
 #ifndef AM_K3_PK
 #define AM_K3_PK 0   // 1 = the 512-row K3's butterflies in packed f32: 40 % fewer VALU instructions, the same 0.170 ms
                      // (tools/pkbench: v_pk_fma_f32 delivers 1.14x the flops of v_fma_f32 at 4 waves per SIMD, not 2x)
@@ -2030,6 +2033,48 @@ __device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4
         float2 step0, step1, step0q, step1q;
         tw_big_pair(pl, (n2 * 32u) & maskN, step0, step0q);
         tw_big_pair(pl, ((n2 + 1u) * 32u) & maskN, step1, step1q);
+#if AM_K3_INTERLEAVE
+        // column 0 goes through its first pass and into LDS before column 1 is touched, and comes out into its
+        // second pass while column 1 is on its way: arithmetic between every two barriers
+        twiddle_chain<16, true, false>(x0, base0, step0, step0q);
+        dif<16, true>(x0);   // inverse over beta: branch value b at x[brev(b)], b = 0..15
+        if (half) {          // the odd-b' branch carries conj(W_32^b)
+#pragma unroll
+            for (int b = 1; b < 16; ++b) x0[brev<16>(b)] = mul_w32<true>(x0[brev<16>(b)], b);
+        }
+#pragma unroll
+        for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = make_float2(x0[brev<16>(b)].x, x0[brev<16>(b)].y);
+        twiddle_chain<16, true, false>(x1, base1, step1, step1q);
+    }
+    dif<16, true>(x1);
+    if (half) {
+#pragma unroll
+        for (int b = 1; b < 16; ++b) x1[brev<16>(b)] = mul_w32<true>(x1[brev<16>(b)], b);
+    }
+    // exchange, one column of the pair at a time: afterwards thread b = hi (0..31) holds
+    // z[a'] = u[a'][b & 15] +- v[a'][b & 15]
+    const float sgn = hi >= 16 ? -1.0f : 1.0f;
+    const int bb = hi & 15;
+    __syncthreads();
+#pragma unroll
+    for (int a2 = 0; a2 < 16; ++a2) {
+        const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
+        x0[a2] = add_signed(u, v, sgn, T{});
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) lds2[c512_idx3(ap, b + 16 * half, cp)] = make_float2(x1[brev<16>(b)].x, x1[brev<16>(b)].y);
+    twiddle_nat<16, true>(x0, w512, w512q);   // conj(W_512^(b*a'))
+    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*32 + b
+    __syncthreads();
+#pragma unroll
+    for (int a2 = 0; a2 < 16; ++a2) {
+        const float2 u = lds2[c512_idx3(a2, bb, cp)], v = lds2[c512_idx3(a2, bb + 16, cp)];
+        x1[a2] = add_signed(u, v, sgn, T{});
+    }
+    twiddle_nat<16, true>(x1, w512, w512q);
+    dif<16, true>(x1);
+#else
         twiddle_chain<16, true, false>(x0, base0, step0, step0q);
         twiddle_chain<16, true, false>(x1, base1, step1, step1q);
     }
@@ -2067,6 +2112,7 @@ __device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4
     twiddle_nat<16, true>(x1, w512, w512q);
     dif<16, true>(x0);   // a at x[brev(a)], n1 = a*32 + b
     dif<16, true>(x1);
+#endif
     k3_finish<5, T, ACC, true>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
 template <int HALF, bool ACC = false, int REDO = 0>   // (REDO: see k3_cols_inv_r16)
