@@ -1609,27 +1609,29 @@ __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const
         float2 step0, step1, step0q, step1q;
         tw_big_pair(pl, (n2 * 16u) & maskN, step0, step0q);
         tw_big_pair(pl, ((n2 + 1) * 16u) & maskN, step1, step1q);
+        // (column 0 through its first pass and into LDS before column 1 is touched, its second pass while column 1
+        // crosses: arithmetic between every two barriers, as in the 512-row kernel)
         twiddle_chain<16, true, false>(x0, base0, step0, step0q);
+        dif<16, true>(x0);   // b at x[brev(b)]
+        // exchange, one column of the pair at a time (32 KB of LDS per workgroup);
+        // afterwards ownership is b = hi, a' = 0..15
+#pragma unroll
+        for (int b = 0; b < 16; ++b) lds2[(hi * 16 + b) * 16 + cp] = x0[brev<16>(b)];
         twiddle_chain<16, true, false>(x1, base1, step1, step1q);
     }
-    dif<16, true>(x0);   // b at x[brev(b)]
     dif<16, true>(x1);
-    // exchange, one column of the pair at a time (32 KB of LDS per workgroup);
-    // afterwards ownership is b = hi, a' = 0..15
-#pragma unroll
-    for (int b = 0; b < 16; ++b) lds2[(hi * 16 + b) * 16 + cp] = x0[brev<16>(b)];
     __syncthreads();
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) x0[ap] = lds2[(ap * 16 + hi) * 16 + cp];
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[(hi * 16 + b) * 16 + cp] = x1[brev<16>(b)];
+    twiddle_nat<16, true>(x0, w256, w256q);
+    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     __syncthreads();
 #pragma unroll
     for (int ap = 0; ap < 16; ++ap) x1[ap] = lds2[(ap * 16 + hi) * 16 + cp];
-    twiddle_nat<16, true>(x0, w256, w256q);
     twiddle_nat<16, true>(x1, w256, w256q);
-    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*16 + b
     dif<16, true>(x1);
     k3_finish<4, float2, ACC, true>(job, scan, ed, lds2, n2_0, out_stride, t, blkA, blkB, out_scale, x0, x1);
 }
