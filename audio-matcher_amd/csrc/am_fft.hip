@@ -2296,17 +2296,17 @@ __device__ __forceinline__ void k3_cols_inv_c1024_tile(unsigned lin, float4* lds
         twiddle_chain<16, true, false>(x0, base0, step0);
         twiddle_chain<16, true, false>(x1, base1, step1);
     }
-    dif<16, true>(x0);   // inverse over beta: b0 at x[brev(b0)]
-    dif<16, true>(x1);
-    if (q) {             // conj(W_64^(b0*q))
-        twiddle_brev<16, true>(x0, w64q);
-        twiddle_brev<16, true>(x1, w64q);
-    }
+    // (column 0 through its first pass and into LDS before column 1's, its second pass while column 1 crosses:
+    // arithmetic between every two barriers, as in the 512-row kernel -- here all 16 waves of the CU meet at each)
     // exchange, one column of the pair at a time: afterwards thread b = hi (0..63) holds
     // z[a'] = sum_q u_q[a'][b & 15] * i^((b >> 4) * q)
     const int bb = hi & 15, m = hi >> 4;
+    dif<16, true>(x0);   // inverse over beta: b0 at x[brev(b0)]
+    if (q) twiddle_brev<16, true>(x0, w64q);   // conj(W_64^(b0*q))
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[c1024_idx3(ap, b + 16 * q, cp)] = x0[brev<16>(b)];
+    dif<16, true>(x1);
+    if (q) twiddle_brev<16, true>(x1, w64q);
     __syncthreads();
 #pragma unroll
     for (int a2 = 0; a2 < 16; ++a2)
@@ -2315,14 +2315,14 @@ __device__ __forceinline__ void k3_cols_inv_c1024_tile(unsigned lin, float4* lds
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; ++b) lds2[c1024_idx3(ap, b + 16 * q, cp)] = x1[brev<16>(b)];
+    twiddle_nat<16, true>(x0, w1024);   // conj(W_1024^(b*a'))
+    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*64 + b
     __syncthreads();
 #pragma unroll
     for (int a2 = 0; a2 < 16; ++a2)
         x1[a2] = radix4_branch<true>(lds2[c1024_idx3(a2, bb, cp)], lds2[c1024_idx3(a2, bb + 16, cp)],
                                      lds2[c1024_idx3(a2, bb + 32, cp)], lds2[c1024_idx3(a2, bb + 48, cp)], m);
-    twiddle_nat<16, true>(x0, w1024);   // conj(W_1024^(b*a'))
     twiddle_nat<16, true>(x1, w1024);
-    dif<16, true>(x0);   // a at x[brev(a)], n1 = a*64 + b
     dif<16, true>(x1);
     k3_finish<6, float2, ACC, true>(job, scan, ed, lds2, n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
 }
