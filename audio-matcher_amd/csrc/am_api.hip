@@ -71,8 +71,11 @@ static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick
 static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
 static std::atomic<long long> g_opt_device_redo{1};      // 0 = failed certificates are redone by the host path only (experiments)
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
+// test hooks (defaults = production behaviour)
+static std::atomic<long long> g_opt_debug_no_realloc{0};     // 1 = a scratch buffer that would be (re)allocated while a call is queueing fails the call
+static std::atomic<long long> g_opt_debug_redo_arm_at{-2};   // >= 0: the device-side redo of a batch arms at that haystack; -1: never; -2: when a failure is seen
 struct Opts {
-    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo;
+    long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo, debug_no_realloc, debug_redo_arm_at;
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
@@ -92,11 +95,33 @@ static const long long kSegmentFrom = 1ll << 22;
 static const long long kSegmentLen = 1ll << 22;
 
 // ---------------------------------------------------------------------------
+// While a batch is being queued (kernels of earlier haystacks still running, or not yet started) no
+// scratch buffer may move: hipFree waits for the device (the overlap of pick and transforms stalls) and a
+// buffer whose contents a later launch still expects would be lost (round 3, gpurun_out/r03q: a peak lost
+// to a flag buffer re-allocated under a running pick).  match_many / match_multi_many size everything
+// before their queueing loops; with the option "debug_no_realloc" an ensure() that would still have to
+// allocate inside such a loop fails the call instead (tests/test_gpu_round4.py).
+static thread_local int t_no_realloc = 0;
+struct QueueingScope {
+    bool on;
+    explicit QueueingScope(bool enable) : on(enable) { if (on) ++t_no_realloc; }
+    ~QueueingScope() { end(); }
+    void end() { if (on) { --t_no_realloc; on = false; } }
+    QueueingScope(const QueueingScope&) = delete;
+    QueueingScope& operator=(const QueueingScope&) = delete;
+};
+static int realloc_refused(const char* what, size_t bytes, size_t cap) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "debug_no_realloc: %s buffer would grow from %zu to %zu bytes while a call is queueing", what, cap, bytes);
+    return fail(AM_ERR_HIP, buf);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return AM_OK;
+        if (t_no_realloc > 0) return realloc_refused("a device", bytes, cap);
         release();
         size_t want = bytes + bytes / 8;
         hipError_t e = hipMalloc(&p, want);
@@ -119,6 +144,7 @@ struct HostBuf {
     unsigned flags = hipHostMallocDefault;
     int ensure(size_t bytes) {
         if (bytes <= cap) return AM_OK;
+        if (t_no_realloc > 0) return realloc_refused("a pinned host", bytes, cap);
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         hipError_t e = hipHostMalloc(&p, bytes, flags);
         if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipHostMalloc"); }
@@ -367,6 +393,8 @@ static Opts snapshot_opts(const am_needle* h) {
     o.needle_group = g_opt_needle_group.load(std::memory_order_relaxed);
     o.dense = g_opt_dense.load(std::memory_order_relaxed);
     o.device_redo = g_opt_device_redo.load(std::memory_order_relaxed);
+    o.debug_no_realloc = g_opt_debug_no_realloc.load(std::memory_order_relaxed);
+    o.debug_redo_arm_at = g_opt_debug_redo_arm_at.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -482,6 +510,11 @@ struct ScanRequest {
     // in (streaming ingest): summary / flag buffers owned by the caller instead of the context's sets, and
     // "launch nothing" (every pair was computed while the samples arrived; only describe what is there)
     DevBuf* ext_stats32; DevBuf* ext_side;
+    // in (streaming ingest): the block count the side buffer is laid out for (0: this launch's own).  The
+    // thresholds sit behind the ballots, i.e. at an offset that depends on the block count: early pairs are
+    // launched under the layout of the announced length and the final pass must keep that layout even
+    // when the real length gives fewer blocks.
+    long long side_nblocks;
     bool skip_launch;
     bool no_scan;            // in: only the block restriction (range_a, range_b) applies; K3 writes plain scores
     bool work_by_set;        // in: the work matrix of set 1 is the context's second one (kept for a device-side redo)
@@ -647,9 +680,10 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
         if (plan_has_scan(pl->dev) && (hop % kTile) == 0) {
             DevBuf& b32 = scan_req->ext_stats32 ? *scan_req->ext_stats32 : (scan_req->set ? c->stats32_b : c->stats32);
             DevBuf& bwf = scan_req->ext_side ? *scan_req->ext_side : (scan_req->set ? c->wflags_b : c->wflags);
+            const long long side_blocks = std::max(nblocks, scan_req->side_nblocks);
             if ((rc = b32.ensure((size_t)((out_count + 31) / 32) * sizeof(float2)))) return rc;
-            if ((rc = bwf.ensure(sparse_bytes(nblocks, pl->dev)))) return rc;
-            fill_scan_cfg(&scan, b32.p, bwf.p, nblocks, pl->dev, scan_req->margin, scan_req->hist_min, scan_req->seg_c, scan_req->seg_d);
+            if ((rc = bwf.ensure(sparse_bytes(side_blocks, pl->dev)))) return rc;
+            fill_scan_cfg(&scan, b32.p, bwf.p, side_blocks, pl->dev, scan_req->margin, scan_req->hist_min, scan_req->seg_c, scan_req->seg_d);
             scan_req->fused = true;
             scan_req->sparse = sparse_view(scan, hop, pl->dev);
         }
@@ -684,6 +718,50 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
         job.first_pair = 0;
         scan_req->redo_job = job; scan_req->redo_pl = pl->dev; scan_req->redo_scale = k3scale; scan_req->redo_half = hs.level;
         scan_req->redo_npairs = (int)npairs; scan_req->redo_work = (const float2*)wk.p; scan_req->redo_cfg = scan;
+    }
+    return AM_OK;
+}
+
+// What the transforms of one haystack need of the context's scratch buffers, so that a batch can size them
+// once, for its largest haystack, before anything is queued (see QueueingScope).  Also builds the plan and
+// the needle spectrum the haystack will use (building one runs kernels and waits for them).
+struct Footprint {
+    size_t work = 0, stats32 = 0, side = 0;
+    long long npairs = 0;
+    void take(const Footprint& f) {
+        work = std::max(work, f.work); stats32 = std::max(stats32, f.stats32); side = std::max(side, f.side);
+        npairs = std::max(npairs, f.npairs);
+    }
+};
+static int correlation_footprint(am_needle* h, const Opts& o, long long out_count, Footprint* f) {
+    if (needle_is_segmented(h, o)) {
+        int rc = needle_segments(h);
+        if (rc) return rc;
+        Opts os = o;
+        os.half = 0;
+        for (am_needle* sub : h->segments) {
+            Footprint one;
+            if ((rc = correlation_footprint(sub, os, out_count, &one))) return rc;
+            f->work = std::max(f->work, one.work);   // (plain scores: no summary, no flags)
+        }
+        return AM_OK;
+    }
+    if (h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0) return AM_OK;
+    Geometry g{};
+    int rc = plan_geometry(h->n, out_count, o, &g);
+    if (rc) return rc;
+    const Plan* pl = nullptr;
+    if ((rc = get_plan(h->ctx, g.logN, &pl))) return rc;
+    const float2* hc = nullptr;
+    if ((rc = needle_spectrum(h, pl, &hc))) return rc;
+    const HalfScale hs = half_scale(h, o, pl->dev);
+    if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hc))) return rc;
+    const long long ppg = std::min(std::max<long long>(1, o.pairs_per_group), g.npairs);
+    f->work = std::max(f->work, (size_t)ppg * (size_t)g.N * sizeof(float2));
+    f->npairs = std::max(f->npairs, g.npairs);
+    if (plan_has_scan(pl->dev) && (g.hop % kTile) == 0) {
+        f->stats32 = std::max(f->stats32, (size_t)((out_count + 31) / 32) * sizeof(float2));
+        f->side = std::max(f->side, sparse_bytes(g.nblocks, pl->dev));
     }
     return AM_OK;
 }
@@ -871,9 +949,10 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
 // as slices of the global score array; a window shorter than the needle has
 // no valid lag and is skipped.  `widths` (optional) receives within.len() of each window.
 static void make_segments(size_t len, size_t s, const am_match_params* p, std::vector<Segment>& segs,
-                          std::vector<size_t>* widths = nullptr) {
+                          std::vector<size_t>* widths = nullptr, size_t max_windows = (size_t)-1) {
     const unsigned long long window = p->chunk + p->overlap;
-    for (unsigned long long off = 0; off < len; off += p->chunk) {
+    size_t i = 0;
+    for (unsigned long long off = 0; off < len && i < max_windows; off += p->chunk, ++i) {
         const unsigned long long w = std::min<unsigned long long>(window, len - off);
         if (w < s) continue;
         Segment sg; sg.a = (long long)off; sg.b = (long long)(off + w - s + 1);
@@ -917,10 +996,22 @@ static inline const void* advance_src(const void* src, size_t elements) {
 
 // Streaming ingest (am_match_stream_*): the block pairs [0, pairs_done) of the one haystack were
 // computed while its samples arrived, into buffers the stream object owns.
+// One part of a haystack that is split over several devices (am_match_part_device, am_pool_match_long*): the
+// buffer holds the samples from window `first_window` on, only its first `max_windows` windows belong to
+// this part (the samples behind them are the last window's overlap), and the peaks come back unmerged, in
+// window order, at their positions in the whole haystack -- calc_chunks up to audio_matcher.rs:131.
+struct PartSpec {
+    size_t max_windows;
+    uint64_t first_sample;            // position of the part's first sample in the whole haystack
+    size_t chunk_base, chunk_total;   // for the per-chunk progress events: this part's first window, windows of the whole haystack
+    std::vector<am_peak>* raw;        // out
+};
+
 struct StreamPre {
     float* scores;
     DevBuf* stats32; DevBuf* side;
     long long pairs_done;
+    long long layout_nblocks;   // the block count the early pairs laid the side buffer out for (ScanRequest::side_nblocks)
 };
 
 // calc_chunks (audio_matcher.rs:88-141) over a batch of resident haystacks =
@@ -983,10 +1074,13 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
 
 static int match_many(am_needle* h, const void* const* d_hays, const size_t* lens, size_t n_hay,
                       const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out, int src_kind = 0,
-                      size_t index_base = 0, size_t index_stride = 1, bool fire_hooks = true, const StreamPre* pre = nullptr) {
+                      size_t index_base = 0, size_t index_stride = 1, bool fire_hooks = true, const StreamPre* pre = nullptr,
+                      const PartSpec* part = nullptr) {
     Ctx* c = h->ctx;
     const Opts o = snapshot_opts(h);
-    const Hooks hooks = fire_hooks ? snapshot_hooks() : Hooks{};
+    Hooks hooks = fire_hooks ? snapshot_hooks() : Hooks{};
+    if (part) hooks.fn = nullptr;   // (the caller reports the whole haystack; the chunks report themselves, below)
+    if (part && n_hay != 1) return fail(AM_ERR_INVALID_ARG, "internal: a part is one haystack");
     // local haystack k is item G(k) of the caller's batch: out, n_out and the progress
     // callbacks use that index (pool submit threads pass their shard: base + k * stride)
     auto G = [&](size_t k) { return index_base + k * index_stride; };
@@ -1020,7 +1114,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         tail_off[k] = (int)tail_segs.size();
         if (d_hays[k] && lens[k] >= s) {
             std::vector<Segment> one; std::vector<size_t> w1;
-            make_segments(lens[k], s, p, one, &w1);
+            make_segments(lens[k], s, p, one, &w1, part ? part->max_windows : (size_t)-1);
             n_chunks[k] = (int)one.size();
             for (size_t i = 0; i < one.size(); ++i) {
                 if (my && w1[i] != window) { tail_segs.push_back(one[i]); tail_w.push_back(w1[i]); }
@@ -1057,6 +1151,22 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         if ((rc = c->scores_b.ensure(max_scores * sizeof(float)))) return rc;
         if ((rc = c->peaks_b.ensure(sizeof(am_peak) * max_segs * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     }
+    // ... and the transforms' own buffers -- work matrix, level-0 summary, ballots and thresholds -- for the
+    // haystack that needs the most of each: a ragged batch whose later haystacks are longer must not free
+    // and re-allocate them under the kernels of the earlier ones (plans and needle spectra are built here too)
+    Footprint need;
+    for (size_t k = 0; k < n_hay; ++k) {
+        if (n_chunks[k] == 0 || seg_off[k + 1] == seg_off[k]) continue;
+        Footprint one;
+        if ((rc = correlation_footprint(h, o, (long long)(lens[k] - s + 1), &one))) return rc;
+        need.take(one);
+    }
+    for (int set = 0; set < (overlap ? 2 : 1); ++set) {
+        if (need.work && (rc = (set ? c->work_b : c->work).ensure(need.work))) return rc;
+        if (pre) continue;   // (streaming ingest brings its own summary and flag buffers)
+        if (need.stats32 && (rc = (set ? c->stats32_b : c->stats32).ensure(need.stats32))) return rc;
+        if (need.side && (rc = (set ? c->wflags_b : c->wflags).ensure(need.side))) return rc;
+    }
     // one spare header behind the main ones serves the single-chunk passes below; the arena
     // holds every list of one haystack in the worst case plus a few entries per chunk
     // (bounded: a chunk whose list finds no room is picked again on its own below)
@@ -1084,26 +1194,29 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     // second stream, no host round trip.  (Single calls redo such a chunk from the host, below.)
     const bool device_redo = overlap && sparse_ok && !needle_is_segmented(h, o) && o.device_redo != 0;
     if (device_redo) {   // sized once for the haystack with the most block pairs: no pick of the batch waits for an allocation
-        long long most = 1;
-        for (size_t k = 0; k < n_hay; ++k) {
-            Geometry g{};
-            if (n_chunks[k] && plan_geometry(s, (long long)(lens[k] - s + 1), o, &g) == AM_OK) most = std::max(most, g.npairs);
-        }
         for (int set = 0; set < 2; ++set)
-            if ((rc = c->redo_pairs[set].ensure(sizeof(int) * (size_t)most))) return rc;
+            if ((rc = c->redo_pairs[set].ensure(sizeof(int) * (size_t)std::max<long long>(need.npairs, 1)))) return rc;
     }
     SegHeader* h_hdr = static_cast<SegHeader*>(c->hdr.p);
     auto chunk_events = [&](size_t k, int stage) {
         if (hooks.chunk_fn)
             for (int i = 0; i < n_chunks[k]; ++i)
-                hooks.chunk_fn(hooks.chunk_user, G(k), (size_t)i, (size_t)n_chunks[k], stage);
+                hooks.chunk_fn(hooks.chunk_user, G(k), (part ? part->chunk_base : 0) + (size_t)i,
+                               part ? part->chunk_total : (size_t)n_chunks[k], stage);
     };
     size_t seq = 0;
-    bool redo_armed = device_redo && h->redo_armed_left[sm] > 0;
+    // Which path a failed chunk takes -- redone on the device, or from the host after the call -- depends on
+    // when the first failure flag becomes visible to this loop: a race between host and GPU that no test can
+    // steer.  The results are identical either way; "debug_redo_arm_at" pins the switch-over to a haystack
+    // index (0: armed from the start, -1: never) so that both paths and the switch are tested deterministically.
+    const bool arm_forced = o.debug_redo_arm_at >= -1;
+    bool redo_armed = device_redo && (arm_forced ? o.debug_redo_arm_at == 0 : h->redo_armed_left[sm] > 0);
+    QueueingScope queueing(o.debug_no_realloc != 0);
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (n_chunks[k] == 0) continue;
-        if (device_redo && !redo_armed && (k & 3) == 0) {
+        if (device_redo && arm_forced) redo_armed = o.debug_redo_arm_at >= 0 && (long long)k >= o.debug_redo_arm_at;
+        else if (device_redo && !redo_armed && (k & 3) == 0) {
             // (the flags of the haystacks queued so far: written by their picks, whenever those have run)
             const volatile unsigned char* f = h_fail;
             for (int i = 0; i < seg_off[k] && !redo_armed; ++i) redo_armed = f[i] != 0;
@@ -1123,7 +1236,6 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         if (redo_armed) {
             Geometry g{};
             if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
-            if ((rc = c->redo_pairs[set].ensure(sizeof(int) * (size_t)g.npairs))) return rc;
             AM_HIP(hipMemsetAsync(c->redo_pairs[set].p, 0, sizeof(int) * (size_t)g.npairs, c->stream));
             d_redo = static_cast<int*>(c->redo_pairs[set].p);
         }
@@ -1136,6 +1248,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             if ((rc = plan_geometry(s, out_count, o, &g))) return rc;
             d_scores = pre->scores;
             scan.ext_stats32 = pre->stats32; scan.ext_side = pre->side;
+            scan.side_nblocks = pre->layout_nblocks;
             scan.range_a = std::min(pre->pairs_done, g.npairs) * 2 * g.hop;
             scan.range_b = out_count;
             scan.skip_launch = scan.range_a >= out_count;
@@ -1166,12 +1279,13 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
         ++seq;
     }
+    queueing.end();
     AM_HIP(hipStreamSynchronize(c->stream));   // the headers are in host memory once the peak kernels have finished
     if (overlap) AM_HIP(hipStreamSynchronize(c->stream2));
     scan.set = 0;
     scan.before_k3 = nullptr;
     scan.bad = nullptr;
-    scan.ext_stats32 = nullptr; scan.ext_side = nullptr; scan.skip_launch = false;   // (the single-chunk passes below work in the context's own buffers)
+    scan.ext_stats32 = nullptr; scan.ext_side = nullptr; scan.side_nblocks = 0; scan.skip_launch = false;   // (the single-chunk passes below work in the context's own buffers)
     scan.range_a = 0; scan.range_b = 0;
     int worst = AM_OK;
     std::vector<am_peak> all;
@@ -1292,7 +1406,12 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             } else append_header_peaks(hd, own, all);
             for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }   // audio_matcher.rs:126
         }
-        rc = merge_peaks(all, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
+        if (part) {   // unmerged, in window order (audio_matcher.rs:132-133), at their positions in the whole haystack
+            for (am_peak& q : all) { q.start += part->first_sample; q.end += part->first_sample; }
+            part->raw->insert(part->raw->end(), all.begin(), all.end());
+            n_out[G(k)] = all.size();
+            rc = AM_OK;
+        } else rc = merge_peaks(all, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
         chunk_events(k, 1);
         if (hooks.fn) hooks.fn(hooks.user, G(k), 1, (size_t)n_chunks[k]);
         if (rc == AM_ERR_CAPACITY) worst = rc;
@@ -1302,7 +1421,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         const long long keep = h->opt_half;
         h->opt_half = 0;
         rc = match_many(h, &d_hays[k], &lens[k], 1, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)], src_kind,
-                        0, 1, false);
+                        0, 1, false, nullptr, part);
         h->opt_half = keep;
         chunk_events(k, 1);
         if (hooks.fn) hooks.fn(hooks.user, G(k), 1, (size_t)n_chunks[k]);
@@ -1420,6 +1539,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     // result headers of (haystack k, needle j): nsegs entries per needle, the haystack's slice inside
     auto hdr_of = [&](size_t k, size_t j) { return (int)(j * nsegs) + seg_off[k]; };
     size_t seq = 0;
+    QueueingScope queueing(o.debug_no_realloc != 0);
     for (size_t k = 0; k < n_hay; ++k) {
         const int ns = seg_off[k + 1] - seg_off[k];
         if (ns == 0) continue;
@@ -1485,6 +1605,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             ++seq;
         }
     }
+    queueing.end();
     AM_HIP(hipStreamSynchronize(c->stream));
     if (overlap) AM_HIP(hipStreamSynchronize(c->stream2));
     int worst = AM_OK;
@@ -1610,6 +1731,7 @@ struct am_stream {
     bool early = false;               // block pairs may be launched before the length is known
     long long pairs_done = 0;
     am::Geometry geo{};               // the provisional block layout (from the capacity)
+    float margin = 0.f;               // the write-threshold margin the early pairs were launched with (< 0: every run written)
     bool failed = false;
 };
 
@@ -1937,7 +2059,16 @@ int am_match_stream_push(am_stream* st, const void* samples, size_t n) {
     scan.hist_min = h->hist_min(st->p.scale == AM_SCALE_LIB ? 1 : 0);
     scan.seg_c = (long long)st->p.chunk;
     scan.seg_d = (long long)(st->p.chunk + st->p.overlap) - (long long)h->n;
+    if (st->pairs_done > 0 && scan.margin != st->margin) {
+        // "dense_scores" changed between two pushes: the early pairs were written under another rule than the
+        // rest would be -- start over at finish
+        st->early = false; st->pairs_done = 0;
+        AM_HIP(hipStreamSynchronize(st->copy_stream));
+        return AM_OK;
+    }
+    st->margin = scan.margin;
     scan.ext_stats32 = &st->stats32; scan.ext_side = &st->side;
+    scan.side_nblocks = g.nblocks;
     scan.range_a = st->pairs_done * 2 * g.hop;
     scan.range_b = ready * 2 * g.hop;
     AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));   // the kernels read what this push has copied
@@ -1964,19 +2095,26 @@ int am_match_stream_finish(am_stream* st, am_peak* out, size_t cap, size_t* n_ou
     if (len) {
         AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));
         const void* src = st->hay.p;
-        StreamPre pre{(float*)st->scores.p, &st->stats32, &st->side, st->pairs_done};
+        StreamPre pre{(float*)st->scores.p, &st->stats32, &st->side, st->pairs_done, st->geo.nblocks};
         bool use_pre = st->early && st->pairs_done > 0;
         if (use_pre) {
-            // the layout the whole haystack gets must be the one the early pairs were computed in
+            // the layout the whole haystack gets must be the one the early pairs were computed in (the side
+            // buffer keeps the offsets of the announced length: StreamPre::layout_nblocks), and so must the rule
+            // by which raw scores are written: with another margin (dense_scores switched, or a prominence bound
+            // that is no longer positive) the pick would read runs the early pairs never wrote
             Geometry fin{};
             const Opts o = snapshot_opts(h);
-            if (len < h->n || plan_geometry(h->n, (long long)(len - h->n + 1), o, &fin) || fin.logN != st->geo.logN || fin.hop != st->geo.hop)
+            const float margin = (st->p.scale != AM_SCALE_MY && !o.dense && st->p.min_prominence > 0.f) ? 0.5f * st->p.min_prominence : -1.0f;
+            if (len < h->n || plan_geometry(h->n, (long long)(len - h->n + 1), o, &fin) || fin.logN != st->geo.logN || fin.hop != st->geo.hop ||
+                fin.nblocks > st->geo.nblocks || margin != st->margin)
                 use_pre = false;
         }
         rc = match_many(h, &src, &len, 1, &st->p, out, cap, n_out, st->fmt, 0, 1, true, use_pre ? &pre : nullptr);
     }
-    // ready for the next file of the same (announced) size
+    // ready for the next file of the same (announced) size; a stream that had to give up its early pairs (an
+    // option changed under it) starts afresh
     st->len = 0; st->pairs_done = 0;
+    if (!st->early && st->cap) (void)stream_layout(st);
     return rc;
 }
 
@@ -2298,6 +2436,31 @@ struct PoolJob {
     int fmt;   // AM_FMT_*: one f32 mono sample and one i16 stereo frame are both 4 bytes
 };
 
+// A resident haystack must live on the device of the slot that matches it (haystack k on slot k mod n_dev):
+// the kernels of that device would otherwise read it over xGMI, or fault.  Ask the runtime instead of
+// trusting the caller.
+int check_resident(const void* ptr, int device, size_t index) {
+    hipPointerAttribute_t attr{};
+    const hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    char buf[200];
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(buf, sizeof(buf), "haystack %zu: not a device pointer the runtime knows (%s)", index, hipGetErrorString(e));
+        return fail(AM_ERR_INVALID_ARG, buf);
+    }
+    if (attr.type == hipMemoryTypeManaged) return AM_OK;
+    if (attr.type != hipMemoryTypeDevice) {
+        snprintf(buf, sizeof(buf), "haystack %zu: host memory passed to a _device entry point", index);
+        return fail(AM_ERR_INVALID_ARG, buf);
+    }
+    if (attr.device != device) {
+        snprintf(buf, sizeof(buf), "haystack %zu lives on device %d but its pool slot runs on device %d (haystack k belongs on slot k mod n_dev)",
+                 index, attr.device, device);
+        return fail(AM_ERR_INVALID_ARG, buf);
+    }
+    return AM_OK;
+}
+
 int slot_match(am_pool::Slot& sl, const PoolJob& job, const void* const* ptrs, const size_t* ln, size_t count,
                const am_match_params* p, am_peak* out, size_t cap, size_t* n_out, size_t first, size_t stride) {
     am_needle* h = sl.needle;
@@ -2318,6 +2481,8 @@ int slot_run_device(am_pool::Slot& sl, const PoolJob& job, size_t slot, size_t n
     for (size_t i = 0; i < count; ++i) { ptrs[i] = d_hays[first + i * stride]; ln[i] = lens[first + i * stride]; }
     int rc = check_needle(sl.needle);
     if (rc) return rc;
+    for (size_t i = 0; i < count; ++i)
+        if (ptrs[i] && ln[i] && (rc = check_resident(ptrs[i], sl.device, first + i * stride))) return rc;
     return slot_match(sl, job, ptrs.data(), ln.data(), count, p, out, cap, n_out, first, stride);
 }
 
@@ -2453,6 +2618,155 @@ int am_pool_match_multi_batch_device(am_pool* pool, const void* const* d_haystac
     return pool_run(pool, PoolJob{true, sample_format}, d_haystacks, lens, n_hay, p, out, cap_per_pair, n_out, false);
 }
 
+// ---- one long haystack over several devices ---------------------------------------------
+// calc_chunks fans the windows of ONE haystack out over its workers (audio_matcher.rs:104-131) and sorts and
+// filters the union afterwards (:132-140).  The same split here: contiguous window ranges per part, each part's
+// buffer reaching to the end of its last window (the overlap tail = the S - 1 halo of SURVEY.md 8e and more),
+// the windows of a part matched as one haystack of their own, ONE merge over all parts.
+int am_long_plan(size_t len, size_t needle_len, const am_match_params* p, size_t n_parts, size_t part,
+                 size_t* first_window, size_t* n_windows, size_t* first_sample, size_t* n_samples) {
+    if (!p || !first_window || !n_windows || !first_sample || !n_samples || n_parts == 0 || part >= n_parts || needle_len == 0)
+        return fail(AM_ERR_INVALID_ARG, "bad part");
+    if (p->chunk == 0) return fail(AM_ERR_INVALID_ARG, "chunk must be > 0");
+    // windows that yield scores: i * chunk < len and min(chunk + overlap, len - i * chunk) >= needle_len (make_segments)
+    const unsigned long long window = p->chunk + p->overlap;
+    size_t nv = 0;
+    if (len >= needle_len && window >= needle_len) {
+        // the last offset whose window is long enough: off <= len - needle_len
+        nv = (size_t)((len - needle_len) / p->chunk) + 1;
+    }
+    const size_t w0 = nv * part / n_parts, w1 = nv * (part + 1) / n_parts;
+    *first_window = w0;
+    *n_windows = w1 - w0;
+    *first_sample = w0 * (size_t)p->chunk;
+    *n_samples = 0;
+    if (w1 > w0) {
+        const unsigned long long end = std::min<unsigned long long>(len, (unsigned long long)(w1 - 1) * p->chunk + window);
+        *n_samples = (size_t)(end - (unsigned long long)*first_sample);
+    }
+    return AM_OK;
+}
+
+int am_match_part_device(const am_needle* hc, const void* d_part, size_t n_samples, int sample_format, const am_match_params* p,
+                         size_t n_windows, uint64_t first_sample, am_peak* out, size_t cap, size_t* n_out) {
+    am_needle* h = const_cast<am_needle*>(hc);
+    int rc = check_needle(h);
+    if (rc) return rc;
+    if (!p || !n_out || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (sample_format != AM_FMT_F32_MONO && sample_format != AM_FMT_S16_STEREO) return fail(AM_ERR_INVALID_ARG, "bad sample format");
+    *n_out = 0;
+    if (n_windows == 0 || n_samples == 0) return AM_OK;
+    if (!d_part) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::lock_guard<std::recursive_mutex> lk(h->ctx->mu);
+    std::vector<am_peak> raw;
+    PartSpec part{n_windows, first_sample, 0, n_windows, &raw};
+    size_t n = 0;
+    if ((rc = match_many(h, &d_part, &n_samples, 1, p, nullptr, 0, &n, sample_format, 0, 1, true, nullptr, &part))) return rc;
+    *n_out = raw.size();
+    for (size_t i = 0; i < raw.size() && i < cap; ++i) out[i] = raw[i];
+    if (raw.size() > cap) return fail(AM_ERR_CAPACITY, "peak output buffer too small");
+    return AM_OK;
+}
+
+int am_merge_peaks(const am_match_params* p, const am_peak* peaks, size_t n, am_peak* out, size_t cap, size_t* n_out) {
+    if (!p || !n_out || (!peaks && n) || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    std::vector<am_peak> all(peaks, peaks + n);
+    return merge_peaks(all, p, out, cap, n_out);
+}
+
+namespace {
+
+int pool_long(am_pool* pool, const void* host_hay, const void* const* d_parts, size_t len, int fmt, const am_match_params* p,
+              am_peak* out, size_t cap, size_t* n_out) {
+    if (!pool || !p || !n_out || (!out && cap) || (!host_hay && !d_parts)) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    if (fmt != AM_FMT_F32_MONO && fmt != AM_FMT_S16_STEREO) return fail(AM_ERR_INVALID_ARG, "bad sample format");
+    std::lock_guard<std::mutex> lk(pool->mu);
+    *n_out = 0;
+    const size_t nslots = pool->slots.size();
+    if (nslots == 0) return fail(AM_ERR_INVALID_ARG, "empty pool");
+    if (pool->slots[0].needles.size() != 1)
+        return fail(AM_ERR_INVALID_ARG, "this pool holds several needles: am_pool_match_long takes a single-needle pool");
+    if (len == 0) return AM_OK;
+    const size_t s = pool->slots[0].needle->n;
+    struct Part { size_t w0, nw, a, n; };
+    std::vector<Part> parts(nslots);
+    size_t total_windows = 0;
+    for (size_t i = 0; i < nslots; ++i) {
+        int rc = am_long_plan(len, s, p, nslots, i, &parts[i].w0, &parts[i].nw, &parts[i].a, &parts[i].n);
+        if (rc) return rc;
+        total_windows += parts[i].nw;
+    }
+    const Hooks hooks = snapshot_hooks();
+    if (hooks.fn) hooks.fn(hooks.user, 0, 0, total_windows);
+    std::vector<std::vector<am_peak>> raw(nslots);
+    std::vector<int> rcs(nslots, AM_OK);
+    std::vector<std::string> errs(nslots);
+    std::vector<std::thread> threads;
+    for (size_t i = 0; i < nslots; ++i)
+        threads.emplace_back([&, i] {
+            const Part& pt = parts[i];
+            if (pt.nw == 0) return;
+            am_pool::Slot& sl = pool->slots[i];
+            int rc = check_needle(sl.needle);   // hipSetDevice for this thread
+            const void* src = nullptr;
+            if (rc == AM_OK && d_parts) {
+                src = d_parts[i];
+                if (!src) rc = fail(AM_ERR_INVALID_ARG, "null part pointer");
+                else rc = check_resident(src, sl.device, i);
+            } else if (rc == AM_OK) {
+                if (pt.n * 4 > sl.ring_cap) {   // (the ring of the host-buffer batch path: its first half holds the part)
+                    for (void*& r : sl.ring) { if (r) (void)hipFree(r); r = nullptr; }
+                    sl.ring_cap = 0;
+                    for (void*& r : sl.ring) {
+                        const hipError_t e = hipMalloc(&r, pt.n * 4);
+                        if (e != hipSuccess) { r = nullptr; rc = hip_fail(e, "hipMalloc(pool ring)"); break; }
+                    }
+                    if (rc == AM_OK) sl.ring_cap = pt.n * 4;
+                }
+                if (rc == AM_OK) {
+                    hipError_t e = hipMemcpyAsync(sl.ring[0], static_cast<const char*>(host_hay) + 4 * pt.a, pt.n * 4, hipMemcpyHostToDevice,
+                                                  sl.copy_stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(sl.copy_stream);
+                    if (e != hipSuccess) rc = hip_fail(e, "host-to-device copy (long haystack)");
+                    src = sl.ring[0];
+                }
+            }
+            if (rc == AM_OK) {
+                am_needle* h = sl.needle;
+                std::lock_guard<std::recursive_mutex> lk2(h->ctx->mu);
+                PartSpec spec{pt.nw, (uint64_t)pt.a, pt.w0, total_windows, &raw[i]};
+                size_t n = 0;
+                rc = match_many(h, &src, &pt.n, 1, p, nullptr, 0, &n, fmt, 0, 1, true, nullptr, &spec);
+            }
+            rcs[i] = rc;
+            if (rc) errs[i] = t_err;
+        });
+    for (std::thread& th : threads) th.join();
+    for (size_t i = 0; i < nslots; ++i)
+        if (rcs[i]) { t_err = errs[i]; return rcs[i]; }
+    // flatten in window order, then ONE sort + overshadow pass over the union (audio_matcher.rs:132-140): a peak
+    // next to a cut sees its neighbour from the other part, exactly as in a single call
+    std::vector<am_peak> all;
+    for (size_t i = 0; i < nslots; ++i) all.insert(all.end(), raw[i].begin(), raw[i].end());
+    const int rc = merge_peaks(all, p, out, cap, n_out);
+    if (hooks.fn) hooks.fn(hooks.user, 0, 1, total_windows);
+    return rc;
+}
+
+}  // namespace
+
+int am_pool_match_long(am_pool* pool, const void* haystack, size_t len, int sample_format, const am_match_params* p,
+                       am_peak* out, size_t cap, size_t* n_out) {
+    if (!haystack && len) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    return pool_long(pool, haystack, nullptr, len, sample_format, p, out, cap, n_out);
+}
+
+int am_pool_match_long_device(am_pool* pool, const void* const* d_parts, size_t len, int sample_format, const am_match_params* p,
+                              am_peak* out, size_t cap, size_t* n_out) {
+    if (!d_parts) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    return pool_long(pool, nullptr, d_parts, len, sample_format, p, out, cap, n_out);
+}
+
 int am_pool_needle_count(const am_pool* pool, size_t* n_needles) {
     if (!pool || !n_needles) return fail(AM_ERR_INVALID_ARG, "null pointer");
     *n_needles = pool->slots.empty() ? 0 : pool->slots[0].needles.size();
@@ -2517,6 +2831,8 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "debug_no_realloc")) { g_opt_debug_no_realloc = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "debug_redo_arm_at")) { g_opt_debug_redo_arm_at = value < -1 ? -2 : value; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
         if (value < 1 || value > kMaxNeedleGroup) return fail(AM_ERR_INVALID_ARG, "needle_group out of range");
         g_opt_needle_group = value; return AM_OK;
@@ -2537,6 +2853,8 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
+    if (!strcmp(key, "debug_no_realloc")) { *value = g_opt_debug_no_realloc; return AM_OK; }
+    if (!strcmp(key, "debug_redo_arm_at")) { *value = g_opt_debug_redo_arm_at; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }
     return fail(AM_ERR_INVALID_ARG, "unknown option");
 }

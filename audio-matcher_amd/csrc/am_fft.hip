@@ -2756,7 +2756,8 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
         return hipGetLastError();
     }
     if (accumulate && half) return hipErrorInvalidValue;   // (the accumulating forms exist for the f32 work matrix only)
-    if (accumulate && (plan_has_scan(pl)) && ((reinterpret_cast<uintptr_t>(job.dst) & 7) != 0 || (job.hop & 1) != 0)) return hipErrorInvalidValue;
+    // (a score pointer that is only 4-byte aligned, or an odd hop, takes k3_finish's scalar read-modify-writes: every
+    // score belongs to one thread, so the accumulating form needs no alignment either)
     if (plan_is_c1024(pl)) {
         if (half) return hipErrorInvalidValue;
         if (accumulate) hipLaunchKernelGGL(k3_cols_inv_c1024<true>, dim3((unsigned)npairs * (kN2 >> kColsLog)), dim3(1024), kC1024Lds, st, job, work,

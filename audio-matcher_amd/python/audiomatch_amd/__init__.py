@@ -148,6 +148,16 @@ _SIGNATURES = {
     "am_pool_match_multi_batch_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
                                                    C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t,
                                                    C.POINTER(C.c_size_t)]),
+    "am_long_plan": (C.c_int, [C.c_size_t, C.c_size_t, C.POINTER(AmMatchParams), C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t),
+                               C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "am_match_part_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(AmMatchParams), C.c_size_t,
+                                       C.c_uint64, C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_merge_peaks": (C.c_int, [C.POINTER(AmMatchParams), C.POINTER(AmPeak), C.c_size_t, C.POINTER(AmPeak), C.c_size_t,
+                                 C.POINTER(C.c_size_t)]),
+    "am_pool_match_long": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(AmMatchParams), C.POINTER(AmPeak),
+                                     C.c_size_t, C.POINTER(C.c_size_t)]),
+    "am_pool_match_long_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.c_int, C.POINTER(AmMatchParams),
+                                            C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
     "am_match_stream_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(AmMatchParams), C.POINTER(C.c_void_p)]),
     "am_match_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "am_match_stream_finish": (C.c_int, [C.c_void_p, C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -468,6 +478,36 @@ def _split_batch(buf, counts, k: int, cap: int):
              for b in buf[i * cap: i * cap + counts[i]]] for i in range(k)]
 
 
+def _peaks(buf, n):
+    return [Peak(int(b.start), int(b.end), float(b.height), float(b.prominence)) for b in buf[:n]]
+
+
+def long_plan(length: int, needle_len: int, params: AmMatchParams, n_parts: int, part: int):
+    """am_long_plan: (first_window, n_windows, first_sample, n_samples) of part `part` of one long haystack."""
+    v = [C.c_size_t(0) for _ in range(4)]
+    _check(lib().am_long_plan(length, needle_len, C.byref(params), n_parts, part, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def match_part_device(algo: "HipConvolve", ptr: int, n_samples: int, params: AmMatchParams, n_windows: int, first_sample: int,
+                      fmt: int = Fmt.F32_MONO, cap: int = 4096):
+    """am_match_part_device: the unmerged peaks of one part (window order, positions in the whole haystack)."""
+    buf = (AmPeak * cap)()
+    n = C.c_size_t(0)
+    _check(lib().am_match_part_device(algo._h, ptr, n_samples, int(fmt), C.byref(params), n_windows, first_sample, buf, cap, C.byref(n)))
+    return _peaks(buf, n.value)
+
+
+def merge_peaks(params: AmMatchParams, peaks, cap: int = 4096):
+    """am_merge_peaks: sort by start + the overshadow filter (audio_matcher.rs:132-160)."""
+    k = len(peaks)
+    src = (AmPeak * max(1, k))(*[AmPeak(q.start, q.end, q.height, q.prominence) for q in peaks])
+    buf = (AmPeak * cap)()
+    n = C.c_size_t(0)
+    _check(lib().am_merge_peaks(C.byref(params), src, k, buf, cap, C.byref(n)))
+    return _peaks(buf, n.value)
+
+
 def shard_plan(n_items: int, n_shards: int, shard: int):
     """am_shard_plan: (first, stride, count) of the items shard `shard` owns (k mod n_shards)."""
     a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
@@ -516,6 +556,23 @@ class Pool:
         counts = (C.c_size_t * max(1, k))()
         _check(lib().am_pool_match_batch_device(self._p, arr_p, arr_l, k, C.byref(params), buf, cap_per_hay, counts))
         return _split_batch(buf, counts, k, cap_per_hay)
+
+    def match_long(self, haystack, params: AmMatchParams, fmt: int = Fmt.F32_MONO, cap: int = 4096):
+        """ONE long host haystack split over the pool's slots by window ranges (am_pool_match_long)."""
+        a = np.ascontiguousarray(haystack, dtype=np.float32 if int(fmt) == Fmt.F32_MONO else np.int16)
+        n = a.size if int(fmt) == Fmt.F32_MONO else a.size // 2
+        buf = (AmPeak * cap)()
+        cnt = C.c_size_t(0)
+        _check(lib().am_pool_match_long(self._p, a.ctypes.data, n, int(fmt), C.byref(params), buf, cap, C.byref(cnt)))
+        return _peaks(buf, cnt.value)
+
+    def match_long_device(self, part_ptrs, length: int, params: AmMatchParams, fmt: int = Fmt.F32_MONO, cap: int = 4096):
+        """The same with resident parts: part_ptrs[i] = the samples of part i (long_plan) on slot i's device."""
+        arr = (C.c_void_p * len(part_ptrs))(*part_ptrs)
+        buf = (AmPeak * cap)()
+        cnt = C.c_size_t(0)
+        _check(lib().am_pool_match_long_device(self._p, arr, length, int(fmt), C.byref(params), buf, cap, C.byref(cnt)))
+        return _peaks(buf, cnt.value)
 
     def match_batch_pcm16(self, haystacks, params: AmMatchParams, cap_per_hay: int = 256):
         """Host haystacks as interleaved i16 stereo arrays (2 * frames values; None = skipped)."""

@@ -260,7 +260,8 @@ int am_pool_slot(const am_pool* pool, size_t slot, int* device, const am_needle*
  * writes only its own haystacks' slots.  Returns the worst status over all haystacks. */
 int am_pool_match_batch(am_pool* pool, const float* const* haystacks, const size_t* lens, size_t n_hay,
                         const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
-/* Same with resident haystacks: d_haystacks[k] must live on the device of slot k mod n_dev. */
+/* Same with resident haystacks: d_haystacks[k] must live on the device of slot k mod n_dev (checked with
+ * hipPointerGetAttributes: AM_ERR_INVALID_ARG names the haystack that sits on another device). */
 int am_pool_match_batch_device(am_pool* pool, const float* const* d_haystacks, const size_t* lens, size_t n_hay,
                                const am_match_params* p, am_peak* out, size_t cap_per_hay, size_t* n_out);
 
@@ -282,6 +283,38 @@ int am_pool_match_multi_batch(am_pool* pool, const void* const* haystacks, const
                               const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out);
 int am_pool_match_multi_batch_device(am_pool* pool, const void* const* d_haystacks, const size_t* lens, size_t n_hay, int sample_format,
                                      const am_match_params* p, am_peak* out, size_t cap_per_pair, size_t* n_out);
+
+/* ---- ONE long haystack over several GPUs ------------------------------------------- */
+/* calc_chunks fans the windows of ONE haystack out over its workers (iter.par_bridge().map(..),
+ * audio_matcher.rs:104-131) and sorts and filters the union afterwards (:132-140).  The same split over
+ * devices ("a single very long haystack: shard by chunk ranges with an S-1 halo"): part i of
+ * n_parts owns a contiguous range of windows, its samples reach to the end of its last window (chunk +
+ * overlap, which contains the S - 1 halo), its windows are matched as on one device and ONE merge runs
+ * over all parts, so that a peak next to a cut meets its neighbour from the other part.  The result
+ * equals am_match on the whole buffer: offsets and plateau ends identical, heights and prominences to
+ * f32 rounding (the overlap-save blocks of a part start at the part, not at sample 0).
+ *
+ * am_long_plan is the split as a pure function (no device needed): windows [first_window, first_window +
+ * n_windows) and samples [first_sample, first_sample + n_samples) of part `part`; n_windows may be 0. */
+int am_long_plan(size_t len, size_t needle_len, const am_match_params* p, size_t n_parts, size_t part,
+                 size_t* first_window, size_t* n_windows, size_t* first_sample, size_t* n_samples);
+/* One part: calc_chunks up to audio_matcher.rs:131 (windowing, correlation, find_peaks, offset restore) on
+ * the first n_windows windows of the resident samples d_part[0 .. n_samples); peaks come back UNMERGED, in
+ * window order, positions shifted by first_sample.  For hosts that run one process per GPU: every rank
+ * matches its part, the ranks' lists are concatenated in part order and am_merge_peaks finishes. */
+int am_match_part_device(const am_needle* h, const void* d_part, size_t n_samples, int sample_format, const am_match_params* p,
+                         size_t n_windows, uint64_t first_sample, am_peak* out, size_t cap, size_t* n_out);
+/* sort by position.start + filter_surrounding(!is_overshadowed) (audio_matcher.rs:132-160) on a host list */
+int am_merge_peaks(const am_match_params* p, const am_peak* peaks, size_t n, am_peak* out, size_t cap, size_t* n_out);
+/* The three steps over the slots of a single-needle pool, one thread per slot.  Host buffer: every slot
+ * copies its own sample range over its own link (the copies of n devices run side by side) and matches
+ * it.  _device: d_parts[i] = the samples of part i (am_long_plan with n_parts = the pool's size), resident
+ * on the device of slot i.  sample_format: AM_FMT_*; len in samples / frames.  Progress: haystack index 0,
+ * chunk indices of the whole haystack. */
+int am_pool_match_long(am_pool* pool, const void* haystack, size_t len, int sample_format, const am_match_params* p,
+                       am_peak* out, size_t cap, size_t* n_out);
+int am_pool_match_long_device(am_pool* pool, const void* const* d_parts, size_t len, int sample_format, const am_match_params* p,
+                              am_peak* out, size_t cap, size_t* n_out);
 
 /* ---- progress hooks ---------------------------------------------------------- */
 /* The two-stage progress callbacks of calc_chunks (audio_matcher.rs:102-117, 129:
@@ -328,7 +361,12 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *       identical, this is the worst case of the sparse-score path for measurements.
  *   "device_redo" (0/1, default 1): in a batch, chunks whose sparse-score certificate fails get their dense
  *       inverse pass on the device, beside the next haystack's transforms; 0 = the host path does it
- *       after the call's kernels (results are identical; for measurements). */
+ *       after the call's kernels (results are identical; for measurements).
+ *   test hooks: "debug_no_realloc" (0/1): a scratch buffer that would have to be (re)allocated while a batch
+ *       is being queued fails the call with AM_ERR_HIP instead (every such buffer is sized before the queueing
+ *       loop; this makes a violation visible); "debug_redo_arm_at" (k >= 0: the device-side redo of a batch is
+ *       armed from haystack k of the call on; -1: never; -2, the default: when a failed certificate has been
+ *       seen) -- pins the otherwise timing-dependent choice between the device and the host redo path. */
 int am_set_option(const char* key, long long value);
 int am_get_option(const char* key, long long* value);
 /* "log_n" and "half_pipeline" per needle handle: -1 = follow the process default (initial

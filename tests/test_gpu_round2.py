@@ -77,32 +77,65 @@ def test_k3_truth_table_pairs_through_am_match(gpu):
 
 
 # measured on MI355X (profiles/r03/k1_kat.txt); the asserted bounds leave a factor of about two
-K1_KAT_BOUNDS = {"direct": 1.2e-5, 10: 1.2e-5, 21: 1.2e-5, 22: 1.2e-5}
+K1_KAT_BOUNDS = {"direct": 1.2e-5, 10: 1.2e-5, 21: 1.2e-5, 22: 1.2e-5, 23: 1.2e-5}
+# what the kernels measure today: two units in the last place of 52 (2 x 3.81e-6).  A change that only moves
+# instructions around has cost a third ulp before (round 3, gpurun_out/r03x: 1.53e-5, over the reference's
+# bound) -- this bound makes such a change visible one ulp BEFORE it reaches 1.2e-5.
+K1_KAT_REGRESSION = {"direct": 0.0, 10: 7.63e-6, 21: 7.63e-6, 22: 7.63e-6, 23: 7.63e-6}
+_k1_kat_cache = {}
+
+
+def k1_kat_errors(gpu):
+    """max |error| of the reference's correlation known answer (audio_matcher.rs:490-517) on the direct path and
+    with every transform plan forced; also with the work matrix stored in f16 (recorded, not asserted: f16
+    storage cannot hold 52 to 1.2e-5).  Written to gpurun_out/k1_kat.txt."""
+    import os
+    if _k1_kat_cache:
+        return _k1_kat_cache["errs"], _k1_kat_cache["text"]
+    within = np.arange(-10, 10, dtype=np.float32)
+    expect = np.array([6 * j - 52 for j in range(18)], dtype=np.float32)
+    algo = gpu.HipConvolve([1.0, 2.0, 3.0])
+    errs = {"direct": float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())}
+    for log_n in (10, 21, 22, 23):
+        algo.set_option("log_n", log_n)
+        errs[log_n] = float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())
+    half = {}
+    for log_n in (21, 22):
+        algo.set_option("log_n", log_n)
+        algo.set_option("half_pipeline", 1)
+        half[log_n] = float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())
+        algo.set_option("half_pipeline", -1)
+    text = "K1 KAT (audio_matcher.rs:490-517), max |error| on values up to 52, reference bound 1.2e-5:\n" + \
+           "".join(f"  {'direct summation' if k == 'direct' else 'transform 2^%d' % k}: {v:.3e} (asserted < {K1_KAT_BOUNDS[k]:.1e}, "
+                   f"regression bound {K1_KAT_REGRESSION[k]:.2e})\n" for k, v in errs.items()) + \
+           "".join(f"  transform 2^{k}, half_pipeline = 1 (f16 work matrix; recorded only): {v:.3e}\n" for k, v in half.items())
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "k1_kat.txt"), "w") as f:
+        f.write(text)
+    _k1_kat_cache["errs"], _k1_kat_cache["text"] = errs, text
+    return errs, text
 
 
 def test_k1_known_answer_at_reference_tolerance(gpu):
     """audio_matcher.rs:490-517 at the reference's own ABSOLUTE bound (|diff| < 1.2e-5, :511, on
     values up to 52) -- on the path the library picks for this input (direct summation: exact on
     integer data) and, with the plan forced, on the transform kernels themselves: the generic 2^10
-    plan and both register plans (2^21 = 256 x 8192, 2^22 = 512 x 8192; the 20 samples zero-padded
-    into one block).  The measured errors go to gpurun_out/k1_kat.txt and into the failure text."""
-    import os
-    within = np.arange(-10, 10, dtype=np.float32)
-    expect = np.array([6 * j - 52 for j in range(18)], dtype=np.float32)
-    algo = gpu.HipConvolve([1.0, 2.0, 3.0])
-    errs = {"direct": float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())}
-    for log_n in (10, 21, 22):
-        algo.set_option("log_n", log_n)
-        errs[log_n] = float(np.abs(algo.correlate_with_sample(within, gpu.Mode.Valid, False) - expect).max())
-    text = "K1 KAT (audio_matcher.rs:490-517), max |error| on values up to 52, reference bound 1.2e-5:\n" + \
-           "".join(f"  {'direct summation' if k == 'direct' else 'transform 2^%d' % k}: {v:.3e} (asserted < {K1_KAT_BOUNDS[k]:.1e})\n"
-                   for k, v in errs.items())
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "k1_kat.txt"), "w") as f:
-        f.write(text)
+    plan and the three register plans (2^21 = 256 x 8192, 2^22 = 512 x 8192, 2^23 = 1024 x 8192; the 20
+    samples zero-padded into one block).  The measured errors go to gpurun_out/k1_kat.txt and into the
+    failure text."""
+    errs, text = k1_kat_errors(gpu)
     for k, v in errs.items():
         assert v < K1_KAT_BOUNDS[k], text
+
+
+def test_k1_known_answer_regression_margin(gpu):
+    """A REGRESSION bound, not the reference's: every transform plan reproduces the known answer to two
+    units in the last place of 52 today (7.63e-6); the reference allows 3.1.  A rescheduling that costs the
+    third ulp fails here first, while test_k1_known_answer_at_reference_tolerance still passes."""
+    errs, text = k1_kat_errors(gpu)
+    for k, v in errs.items():
+        assert v <= K1_KAT_REGRESSION[k] * (1 + 1e-3), text
 
 
 # ---------------------------------------------------------------------------

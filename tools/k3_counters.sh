@@ -2,7 +2,7 @@
 # Cache / memory-path counters of the three pipeline kernels on the headline workload (separate --pmc
 # passes of a short bench run, no trace domains): L2 hits and misses, L2 <-> fabric requests, the
 # vector cache's stalls, and the SQ's memory-wait split.  Run on the GPU box from the repo root:
-#   tools/k3_counters.sh gpurun_out/<tag>
+#   tools/k3_counters.sh gpurun_out/<tag>          (EXTRA="--config 4" for the f16 pipeline)
 set -o pipefail
 out=${1:-gpurun_out/k3c}
 mkdir -p "$out"
@@ -17,13 +17,13 @@ for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum" "TCC_WRITE_sum 
            "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
            "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o run -- python3 bench.py $lean > "$out/pass$i.log" 2>&1 \
+  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -o run -- python3 bench.py $lean $EXTRA > "$out/pass$i.log" 2>&1 \
     || { echo "pass $i ($set) failed or timed out" >> "$out/failed.txt"; if grep -q "caught signal" "$out/pass$i.log"; then echo "stopping: the profiler aborted" >> "$out/failed.txt"; break; fi; }
 done
 python3 - "$out" <<'PY'
 import collections, csv, glob, json, sys
 root = sys.argv[1]
-KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": "k2_rows_r16_planes", "k3_cols_inv": "k3_cols_inv_"}
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16_planes", "k2_rows_h16"), "k3_cols_inv": "k3_cols_inv_"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/pass*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -32,7 +32,8 @@ res = {}
 for key, pat in KEYS.items():
     agg = {}
     for name, counters in vals.items():
-        if pat not in name or name.split("(")[0].rstrip().endswith(", 1>"):   # (skip the device-side redo's K3 instantiations)
+        pats = (pat,) if isinstance(pat, str) else pat
+        if not any(p_ in name for p_ in pats) or name.split("(")[0].rstrip().endswith(", 1>"):   # (skip the device-side redo's K3 instantiations)
             continue
         for cname, lst in counters.items():
             gmax = max(g for _, g in lst)
