@@ -74,8 +74,18 @@ static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every 
 // test hooks (defaults = production behaviour)
 static std::atomic<long long> g_opt_debug_no_realloc{0};     // 1 = a scratch buffer that would be (re)allocated while a call is queueing fails the call
 static std::atomic<long long> g_opt_debug_redo_arm_at{-2};   // >= 0: the device-side redo of a batch arms at that haystack; -1: never; -2: when a failure is seen
+// The semantics nothing available offline pins (the crates find_peaks 0.1 and common are absent, no
+// reference test covers these rules).  Defaults = the documented choices of oracle/oracle.c; every alternative exists
+// in the kernels, on the host AND in the checker, so that one run by someone who has the crates settles each with an
+// option instead of a rewrite (DESIGN.md section 3 lists inputs on which the variants differ).
+static std::atomic<long long> g_opt_peak_filter_order{0};   // 0 = prominence, then distance; 1 = distance, then prominence (scipy's order)
+static std::atomic<long long> g_opt_distance_rule{0};       // bit 0: drop at distance <= min_distance (default <); bit 1: between plateau starts (default middles)
+static std::atomic<long long> g_opt_tail_window{0};         // 0 = chunked() emits the shorter windows at the end; 1 = only full-length windows
+static std::atomic<long long> g_opt_surrounding_from{0};    // filter_surrounding's neighbours: 0 = of the sorted, unfiltered sequence; 1 = the neighbour before is the last element kept
 struct Opts {
     long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo, debug_no_realloc, debug_redo_arm_at;
+    long long peak_filter_order, distance_rule, tail_window, surrounding_from;
+    PeakPolicy peak_policy() const { return PeakPolicy{(int)peak_filter_order, (int)(distance_rule & 1), (int)((distance_rule >> 1) & 1)}; }
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
 static const double kMinEfficiency = 0.75;  // hop / N the auto plan accepts
@@ -395,6 +405,10 @@ static Opts snapshot_opts(const am_needle* h) {
     o.device_redo = g_opt_device_redo.load(std::memory_order_relaxed);
     o.debug_no_realloc = g_opt_debug_no_realloc.load(std::memory_order_relaxed);
     o.debug_redo_arm_at = g_opt_debug_redo_arm_at.load(std::memory_order_relaxed);
+    o.peak_filter_order = g_opt_peak_filter_order.load(std::memory_order_relaxed);
+    o.distance_rule = g_opt_distance_rule.load(std::memory_order_relaxed);
+    o.tail_window = g_opt_tail_window.load(std::memory_order_relaxed);
+    o.surrounding_from = g_opt_surrounding_from.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -847,7 +861,7 @@ static int prepare_results(Ctx* c, size_t nhdr, size_t arena_entries, PeakArena*
 // context's segment buffer, result headers at [hdr_off, hdr_off + nsegs).
 static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int seg_off, int nsegs,
                        float min_prom, long long min_dist, const ScanRequest* scan, int hdr_off,
-                       const PeakArena& arena, hipStream_t st = nullptr, bool only_failed = false) {
+                       const PeakArena& arena, const PeakPolicy& pol, hipStream_t st = nullptr, bool only_failed = false) {
     if (!st) st = c->stream;
     const int set = scan ? scan->set : 0;
     DevBuf& bstats = set ? c->stats_b : c->stats;
@@ -882,7 +896,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         ProfScope ps(c, KN_PEAKS, st);
         AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
-                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide, only_failed));
+                            (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide, only_failed, pol));
     }
     return AM_OK;
 }
@@ -894,7 +908,7 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
 // (am_peaks.hip, peaks_big_finish), fetch the survivors.  Synchronous; appends to `all`.
 static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int seg_idx, const Segment& sg,
                           float min_prom, long long min_dist, const ScanRequest* scan, float seg_min,
-                          std::vector<am_peak>& all) {
+                          std::vector<am_peak>& all, const PeakPolicy& pol) {
     const long long a = sg.a, b = std::min(sg.b, n_scores);
     if (b - a >= 0xFFFFFFFFll) return fail(AM_ERR_PEAK_OVERFLOW, "chunk of 2^32 scores or more with more than AM_MAX_PEAKS_PER_CHUNK peaks");
     const SparseScores sp = (scan && scan->fused) ? scan->sparse : SparseScores{nullptr, nullptr, nullptr, 1, 5, 5, 1.0};
@@ -912,7 +926,7 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
     // pass 1: count
     wide.list = nullptr; wide.cap = 0;
     AM_HIP(hipMemcpyAsync(c->wide_ctl.p, &ctl, 24, hipMemcpyHostToDevice, c->stream));
-    AM_HIP(launch_peaks_wide_one(c->stream, d_scores, n_scores, (const float2*)c->stats.p, d_seg, min_prom, min_dist, sp, wide));
+    AM_HIP(launch_peaks_wide_one(c->stream, d_scores, n_scores, (const float2*)c->stats.p, d_seg, min_prom, min_dist, sp, wide, pol));
     unsigned n = 0;
     AM_HIP(hipMemcpyAsync(&n, wide.count, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     AM_HIP(hipStreamSynchronize(c->stream));
@@ -927,11 +941,11 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
     // pass 2: fill the list (in any order)
     wide.list = reinterpret_cast<am_peak*>(base); wide.cap = n;
     AM_HIP(hipMemcpyAsync(c->wide_ctl.p, &ctl, 24, hipMemcpyHostToDevice, c->stream));
-    AM_HIP(launch_peaks_wide_one(c->stream, d_scores, n_scores, (const float2*)c->stats.p, d_seg, min_prom, min_dist, sp, wide));
+    AM_HIP(launch_peaks_wide_one(c->stream, d_scores, n_scores, (const float2*)c->stats.p, d_seg, min_prom, min_dist, sp, wide, pol));
     AM_HIP(hipMemsetAsync(base + off_table, 0xFF, 8 * nb, c->stream));
     AM_HIP(launch_peaks_big_finish(c->stream, wide.list, n, a, min_dist, reinterpret_cast<unsigned long long*>(base + off_keys),
                                    reinterpret_cast<unsigned*>(base + off_idx), reinterpret_cast<long long*>(base + off_table),
-                                   reinterpret_cast<am_peak*>(base + off_out), reinterpret_cast<unsigned*>(base + off_n)));
+                                   reinterpret_cast<am_peak*>(base + off_out), reinterpret_cast<unsigned*>(base + off_n), pol));
     unsigned kept = 0;
     AM_HIP(hipMemcpyAsync(&kept, base + off_n, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     AM_HIP(hipStreamSynchronize(c->stream));
@@ -948,13 +962,14 @@ static int pick_chunk_big(Ctx* c, const float* d_scores, long long n_scores, int
 // windows of common::chunked(chunk + overlap, hop = chunk) (audio_matcher.rs:104)
 // as slices of the global score array; a window shorter than the needle has
 // no valid lag and is skipped.  `widths` (optional) receives within.len() of each window.
-static void make_segments(size_t len, size_t s, const am_match_params* p, std::vector<Segment>& segs,
+// `drop_tail` (option "tail_window" = 1): chunked() yields full-length windows only.
+static void make_segments(size_t len, size_t s, const am_match_params* p, bool drop_tail, std::vector<Segment>& segs,
                           std::vector<size_t>* widths = nullptr, size_t max_windows = (size_t)-1) {
     const unsigned long long window = p->chunk + p->overlap;
     size_t i = 0;
     for (unsigned long long off = 0; off < len && i < max_windows; off += p->chunk, ++i) {
         const unsigned long long w = std::min<unsigned long long>(window, len - off);
-        if (w < s) continue;
+        if (w < s || (drop_tail && w < window)) continue;
         Segment sg; sg.a = (long long)off; sg.b = (long long)(off + w - s + 1);
         segs.push_back(sg);
         if (widths) widths->push_back((size_t)w);
@@ -962,15 +977,20 @@ static void make_segments(size_t len, size_t s, const am_match_params* p, std::v
 }
 
 // sort by start (audio_matcher.rs:135) + filter_surrounding (audio_matcher.rs:136-139)
-static int merge_peaks(std::vector<am_peak>& all, const am_match_params* p, am_peak* out, size_t cap, size_t* n_out) {
+// `from_filtered` (option "surrounding_from" = 1): the neighbour before an element is the last element that was KEPT (a
+// sequential filter); default: both neighbours come from the sorted, unfiltered sequence.
+static int merge_peaks(std::vector<am_peak>& all, const am_match_params* p, bool from_filtered, am_peak* out, size_t cap, size_t* n_out) {
     std::stable_sort(all.begin(), all.end(), [](const am_peak& x, const am_peak& y) { return x.start < y.start; });
     size_t n = 0;
+    am_peak last_kept{};
+    bool have_kept = false;
     for (size_t i = 0; i < all.size(); ++i) {
-        const am_peak* before = i > 0 ? &all[i - 1] : nullptr;
+        const am_peak* before = from_filtered ? (have_kept ? &last_kept : nullptr) : (i > 0 ? &all[i - 1] : nullptr);
         const am_peak* after = i + 1 < all.size() ? &all[i + 1] : nullptr;
         if (is_overshadowed(all[i], before, p->sr, p->overshadow_distance_s) ||
             is_overshadowed(all[i], after, p->sr, p->overshadow_distance_s))
             continue;
+        last_kept = all[i]; have_kept = true;
         if (n < cap) out[n] = all[i];
         ++n;
     }
@@ -1078,6 +1098,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                       const PartSpec* part = nullptr) {
     Ctx* c = h->ctx;
     const Opts o = snapshot_opts(h);
+    const PeakPolicy pol = o.peak_policy();
     Hooks hooks = fire_hooks ? snapshot_hooks() : Hooks{};
     if (part) hooks.fn = nullptr;   // (the caller reports the whole haystack; the chunks report themselves, below)
     if (part && n_hay != 1) return fail(AM_ERR_INVALID_ARG, "internal: a part is one haystack");
@@ -1114,7 +1135,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         tail_off[k] = (int)tail_segs.size();
         if (d_hays[k] && lens[k] >= s) {
             std::vector<Segment> one; std::vector<size_t> w1;
-            make_segments(lens[k], s, p, one, &w1, part ? part->max_windows : (size_t)-1);
+            make_segments(lens[k], s, p, o.tail_window != 0, one, &w1, part ? part->max_windows : (size_t)-1);
             n_chunks[k] = (int)one.size();
             for (size_t i = 0; i < one.size(); ++i) {
                 if (my && w1[i] != window) { tail_segs.push_back(one[i]); tail_w.push_back(w1[i]); }
@@ -1264,7 +1285,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             scan.sparse.redo_pairs = (redo_armed && scan.redo_ok) ? d_redo : nullptr;
         }
         if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence,
-                              (long long)p->min_distance, &scan, seg_off[k], arena, overlap ? c->stream2 : c->stream))) return rc;
+                              (long long)p->min_distance, &scan, seg_off[k], arena, pol, overlap ? c->stream2 : c->stream))) return rc;
         if (scan.fused && scan.sparse.redo_pairs) {
             ScanCfg cfg = scan.redo_cfg;
             cfg.margin = -1.0f;
@@ -1274,7 +1295,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             ScanRequest again = scan;
             again.sparse.redo_pairs = nullptr; again.sparse.fail_flags = nullptr; again.bad = nullptr;
             if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
-                                  &again, seg_off[k], arena, c->stream2, true))) return rc;
+                                  &again, seg_off[k], arena, pol, c->stream2, true))) return rc;
         }
         if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
         ++seq;
@@ -1343,13 +1364,13 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
                 if ((rc = run_correlation(h, o, advance_src(d_hays[k], (size_t)sg.a), (long long)widths[i], 0, (float*)c->scores.p, cnt,
                                           factor, &one, src_kind))) return rc;
                 if ((rc = launch_pick(c, (const float*)c->scores.p, cnt, local_seg, 1, p->min_prominence,
-                                      (long long)p->min_distance, &one, spare_hdr, own))) return rc;
+                                      (long long)p->min_distance, &one, spare_hdr, own, pol))) return rc;
                 AM_HIP(hipStreamSynchronize(c->stream));
                 const SegHeader& hd = h_hdr[spare_hdr];
                 const size_t old = all.size();
                 if (hd.overflow & 1) {
                     if ((rc = pick_chunk_big(c, (const float*)c->scores.p, cnt, local_seg, Segment{0, cnt}, p->min_prominence,
-                                             (long long)p->min_distance, &one, hd.seg_min, all))) return rc;
+                                             (long long)p->min_distance, &one, hd.seg_min, all, pol))) return rc;
                 } else append_header_peaks(hd, own, all);
                 for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }
                 continue;
@@ -1372,12 +1393,12 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             if ((rc = run_correlation(h, o, d_hays[k], (long long)lens[k], 0, (float*)c->scores.p, out_count, factor,
                                       &full, src_kind))) return rc;
             if ((rc = launch_pick(c, (const float*)c->scores.p, out_count, i, 1, p->min_prominence,
-                                  (long long)p->min_distance, &full, spare_hdr, own))) return rc;
+                                  (long long)p->min_distance, &full, spare_hdr, own, pol))) return rc;
             AM_HIP(hipStreamSynchronize(c->stream));
             const SegHeader& hd = h_hdr[spare_hdr];
             if (hd.overflow & 1) {
                 if ((rc = pick_chunk_big(c, (const float*)c->scores.p, out_count, i, segs[i], p->min_prominence,
-                                         (long long)p->min_distance, &full, hd.seg_min, all))) return rc;
+                                         (long long)p->min_distance, &full, hd.seg_min, all, pol))) return rc;
             } else append_header_peaks(hd, own, all);
         }
         // second pass (MyConvolve scaling only): the shorter windows at the end of the haystack
@@ -1396,13 +1417,13 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             if ((rc = run_correlation(h, o, advance_src(d_hays[k], (size_t)sg.a), (long long)tail_w[i], 0, (float*)c->scores.p, cnt,
                                       scale_factor(h, p->scale, tail_w[i]), &one, src_kind))) return rc;
             if ((rc = launch_pick(c, (const float*)c->scores.p, cnt, (int)nsegs + i, 1, p->min_prominence,
-                                  (long long)p->min_distance, &one, spare_hdr, own))) return rc;
+                                  (long long)p->min_distance, &one, spare_hdr, own, pol))) return rc;
             AM_HIP(hipStreamSynchronize(c->stream));
             const SegHeader& hd = h_hdr[spare_hdr];
             const size_t old = all.size();
             if (hd.overflow & 1) {
                 if ((rc = pick_chunk_big(c, (const float*)c->scores.p, cnt, (int)nsegs + i, Segment{0, cnt}, p->min_prominence,
-                                         (long long)p->min_distance, &one, hd.seg_min, all))) return rc;
+                                         (long long)p->min_distance, &one, hd.seg_min, all, pol))) return rc;
             } else append_header_peaks(hd, own, all);
             for (size_t j = old; j < all.size(); ++j) { all[j].start += (uint64_t)sg.a; all[j].end += (uint64_t)sg.a; }   // audio_matcher.rs:126
         }
@@ -1411,7 +1432,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             part->raw->insert(part->raw->end(), all.begin(), all.end());
             n_out[G(k)] = all.size();
             rc = AM_OK;
-        } else rc = merge_peaks(all, p, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
+        } else rc = merge_peaks(all, p, o.surrounding_from != 0, out ? out + G(k) * cap_per_hay : nullptr, cap_per_hay, &n_out[G(k)]);
         chunk_events(k, 1);
         if (hooks.fn) hooks.fn(hooks.user, G(k), 1, (size_t)n_chunks[k]);
         if (rc == AM_ERR_CAPACITY) worst = rc;
@@ -1446,6 +1467,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     am_needle* h0 = needles[0];
     Ctx* c = h0->ctx;
     const Opts o = snapshot_opts(h0);
+    const PeakPolicy pol = o.peak_policy();
     const Hooks hooks = snapshot_hooks();
     auto G = [&](size_t k) { return index_base + k * index_stride; };
     const size_t s = h0->n;
@@ -1481,7 +1503,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     for (size_t k = 0; k < n_hay; ++k) {
         seg_off[k] = (int)segs.size();
         if (!d_hays[k] || lens[k] < s) continue;
-        make_segments(lens[k], s, p, segs);
+        make_segments(lens[k], s, p, o.tail_window != 0, segs);
         const size_t ns = segs.size() - (size_t)seg_off[k];
         if (ns == 0) continue;
         const long long out_count = (long long)(lens[k] - s + 1);
@@ -1600,7 +1622,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
                 AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
             }
             if ((rc = launch_pick(c, d_scores, out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
-                                  &scan, hdr_of(k, j), arena, overlap ? c->stream2 : c->stream))) return rc;
+                                  &scan, hdr_of(k, j), arena, pol, overlap ? c->stream2 : c->stream))) return rc;
             if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
             ++seq;
         }
@@ -1631,7 +1653,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             if (again) { redo.emplace_back(k, j); continue; }
             all.clear();
             for (int i = 0; i < ns; ++i) append_header_peaks(hd[i], arena, all);
-            rc = merge_peaks(all, p, out ? out + slot * cap_per_pair : nullptr, cap_per_pair, &n_out[slot]);
+            rc = merge_peaks(all, p, o.surrounding_from != 0, out ? out + slot * cap_per_pair : nullptr, cap_per_pair, &n_out[slot]);
             if (rc == AM_ERR_CAPACITY) worst = rc;
             else if (rc) return rc;
         }
@@ -1655,16 +1677,17 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
 static int find_peaks_host_array(Ctx* c, const float* d_scores, long long n, float min_prom, long long min_dist,
                                  std::vector<am_peak>& all) {
     int rc;
+    const PeakPolicy pol = snapshot_opts(nullptr).peak_policy();
     Segment sg; sg.a = 0; sg.b = n;
     PeakArena arena{};
     if ((rc = prepare_results(c, 1, AM_MAX_PEAKS_PER_CHUNK, &arena))) return rc;
     if ((rc = c->peaks.ensure(sizeof(am_peak) * AM_MAX_PEAKS_PER_CHUNK))) return rc;
     if ((rc = upload_segments(c, std::vector<Segment>(1, sg)))) return rc;
-    if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr, 0, arena))) return rc;
+    if ((rc = launch_pick(c, d_scores, n, 0, 1, min_prom, min_dist, nullptr, 0, arena, pol))) return rc;
     AM_HIP(hipStreamSynchronize(c->stream));
     const SegHeader hd = *static_cast<const SegHeader*>(c->hdr.p);
     all.clear();
-    if (hd.overflow) return pick_chunk_big(c, d_scores, n, 0, sg, min_prom, min_dist, nullptr, hd.seg_min, all);
+    if (hd.overflow) return pick_chunk_big(c, d_scores, n, 0, sg, min_prom, min_dist, nullptr, hd.seg_min, all, pol);
     append_header_peaks(hd, arena, all);
     return AM_OK;
 }
@@ -2631,7 +2654,9 @@ int am_long_plan(size_t len, size_t needle_len, const am_match_params* p, size_t
     // windows that yield scores: i * chunk < len and min(chunk + overlap, len - i * chunk) >= needle_len (make_segments)
     const unsigned long long window = p->chunk + p->overlap;
     size_t nv = 0;
-    if (len >= needle_len && window >= needle_len) {
+    if (g_opt_tail_window.load(std::memory_order_relaxed)) {   // option "tail_window" = 1: full-length windows only
+        if (len >= window && window >= needle_len) nv = (size_t)((len - window) / p->chunk) + 1;
+    } else if (len >= needle_len && window >= needle_len) {
         // the last offset whose window is long enough: off <= len - needle_len
         nv = (size_t)((len - needle_len) / p->chunk) + 1;
     }
@@ -2671,7 +2696,7 @@ int am_match_part_device(const am_needle* hc, const void* d_part, size_t n_sampl
 int am_merge_peaks(const am_match_params* p, const am_peak* peaks, size_t n, am_peak* out, size_t cap, size_t* n_out) {
     if (!p || !n_out || (!peaks && n) || (!out && cap)) return fail(AM_ERR_INVALID_ARG, "null pointer");
     std::vector<am_peak> all(peaks, peaks + n);
-    return merge_peaks(all, p, out, cap, n_out);
+    return merge_peaks(all, p, snapshot_opts(nullptr).surrounding_from != 0, out, cap, n_out);
 }
 
 namespace {
@@ -2748,7 +2773,7 @@ int pool_long(am_pool* pool, const void* host_hay, const void* const* d_parts, s
     // next to a cut sees its neighbour from the other part, exactly as in a single call
     std::vector<am_peak> all;
     for (size_t i = 0; i < nslots; ++i) all.insert(all.end(), raw[i].begin(), raw[i].end());
-    const int rc = merge_peaks(all, p, out, cap, n_out);
+    const int rc = merge_peaks(all, p, snapshot_opts(nullptr).surrounding_from != 0, out, cap, n_out);
     if (hooks.fn) hooks.fn(hooks.user, 0, 1, total_windows);
     return rc;
 }
@@ -2831,6 +2856,13 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "peak_filter_order")) { g_opt_peak_filter_order = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "distance_rule")) {
+        if (value < 0 || value > 3) return fail(AM_ERR_INVALID_ARG, "distance_rule out of range (bit 0: inclusive, bit 1: between plateau starts)");
+        g_opt_distance_rule = value; return AM_OK;
+    }
+    if (!strcmp(key, "tail_window")) { g_opt_tail_window = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "surrounding_from")) { g_opt_surrounding_from = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "debug_no_realloc")) { g_opt_debug_no_realloc = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "debug_redo_arm_at")) { g_opt_debug_redo_arm_at = value < -1 ? -2 : value; return AM_OK; }
     if (!strcmp(key, "needle_group")) {
@@ -2853,6 +2885,10 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
+    if (!strcmp(key, "peak_filter_order")) { *value = g_opt_peak_filter_order; return AM_OK; }
+    if (!strcmp(key, "distance_rule")) { *value = g_opt_distance_rule; return AM_OK; }
+    if (!strcmp(key, "tail_window")) { *value = g_opt_tail_window; return AM_OK; }
+    if (!strcmp(key, "surrounding_from")) { *value = g_opt_surrounding_from; return AM_OK; }
     if (!strcmp(key, "debug_no_realloc")) { *value = g_opt_debug_no_realloc; return AM_OK; }
     if (!strcmp(key, "debug_redo_arm_at")) { *value = g_opt_debug_redo_arm_at; return AM_OK; }
     if (!strcmp(key, "profile_mask")) { *value = g_opt_profile_mask; return AM_OK; }

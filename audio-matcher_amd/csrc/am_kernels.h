@@ -159,6 +159,14 @@ struct WideState {
     int* tiles;          // kWideTileList entries per chunk: candidate tiles relative to the chunk's first full tile
 };
 constexpr int kWideTileList = 1024;
+// The rules of find_peaks 0.1 that nothing available offline pins (crate source absent, no reference test; SURVEY.md
+// 8c): the defaults are the library's documented choice (oracle/oracle.c), every alternative is implemented in the
+// kernels AND in the checker, so that whoever has the crate flips an option instead of rewriting a kernel.
+struct PeakPolicy {
+    int order;        // 0: prominence filter, then distance filter (default); 1: distance first, then prominence (scipy's order)
+    int inclusive;    // the distance filter drops a peak whose distance to a kept, higher one is  0: < min_distance (default)  1: <= min_distance
+    int from_start;   // ... measured between  0: plateau middles (start + end) / 2 (default)  1: plateau starts
+};
 // A chunk with more than AM_MAX_PEAKS_PER_CHUNK peaks passing the prominence filter (rare: a
 // min_distance shorter than the chunk and a tiny prominence bound).  launch_peaks_wide_one runs the
 // list-building kernel for ONE chunk (wide.state[0] must be 1; wide.cap = 0 only counts);
@@ -167,14 +175,15 @@ constexpr int kWideTileList = 1024;
 // min_distance-wide buckets (each holds at most one kept peak).  Scratch: keys 2 x n x 8 bytes,
 // idx 2 x n x 4 bytes, table ((b - a) / min_distance + 3) x 8 bytes preset to 0xFF.
 hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len, const float2* stats, const Segment* d_seg,
-                                 float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide);
+                                 float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide, const PeakPolicy& pol);
 hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
-                                   unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n);
+                                   unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n,
+                                   const PeakPolicy& pol);
 // only_failed: pick only the chunks whose header says "certificate failed" (after the device-side redo of K3)
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
-                        const WideState& wide, bool only_failed = false);
+                        const WideState& wide, bool only_failed, const PeakPolicy& pol);
 // writes sumsq_parts(n) partial sums (one per workgroup) to d_parts
 int sumsq_parts(long long n);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts);

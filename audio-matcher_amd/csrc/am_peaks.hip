@@ -333,7 +333,21 @@ struct ChunkView {
     SparseScores sp;
     long long a, b;
     float seg_min, min_prom;
+    // PeakPolicy::order == 1 (distance filter first): a maximum that passes the height test but fails the
+    // prominence test still takes part in the distance filter, so it is emitted as well -- with kFailedProm
+    // in place of its prominence -- and removed after that filter (finish_chunk, peaks_big_finish).
+    int keep_failed;
 };
+// the prominence of a maximum that failed the prominence test (compares false with everything)
+__device__ __forceinline__ float failed_prom() { return __uint_as_float(0x7FC00000u); }
+// the position the distance filter measures between (PeakPolicy::from_start)
+__device__ __forceinline__ long long dist_pos(const am_peak& pk, int from_start) {
+    return from_start ? (long long)pk.start : (long long)((pk.start + pk.end) / 2);
+}
+// dropped when closer than min_dist to a kept peak: strictly (default) or inclusively (PeakPolicy::inclusive)
+__device__ __forceinline__ bool too_close(long long d, long long min_dist, int inclusive) {
+    return inclusive ? d <= min_dist : d < min_dist;
+}
 
 // Scan window offsets from `from` in direction STEP until (exclusive) `end`; returns true when a
 // strictly higher score was met (mn = minimum of the scores before it).  Eight scores are
@@ -460,7 +474,7 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
                     rejected = st.y > x;
                 }
             }
-            if (rejected) continue;
+            if (rejected) { if (cv.keep_failed) emit((long long)i, k, x, failed_prom()); continue; }
         }
         // stage 1: flat-topped maximum [i, k) of height x against its kNear neighbours on either side
         // (a side is settled by a strictly higher score, or by the chunk edge)
@@ -469,9 +483,9 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
             const int l_end = wi - 1 - kNear > -1 ? wi - 1 - kNear : -1, r_end = wk + kNear < wn ? wk + kNear : wn;
             float lmn = x, rmn = x;
             const bool dl = side_scan<-1>(win, wi - 1, l_end, x, lmn) || (l_end == -1 && w_lo == a);
-            if (dl && !((x - lmn) >= cv.min_prom)) continue;
+            if (dl && !((x - lmn) >= cv.min_prom)) { if (cv.keep_failed) emit((long long)i, k, x, failed_prom()); continue; }
             const bool dr = side_scan<1>(win, wk, r_end, x, rmn) || (r_end == wn && w_hi == b);
-            if (dr && !((x - rmn) >= cv.min_prom)) continue;
+            if (dr && !((x - rmn) >= cv.min_prom)) { if (cv.keep_failed) emit((long long)i, k, x, failed_prom()); continue; }
             if (dl && dr) {
                 emit((long long)i, k, x, x - fmaxf(lmn, rmn));
                 continue;
@@ -489,9 +503,9 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
         if (cd.pe <= w_hi) {
             float lmn = cd.h, rmn = cd.h;
             const bool dl = side_scan_wave<-1>(win, (int)(cd.ps - 1 - w_lo), -1, cd.h, lmn, lane) || w_lo == a;
-            if (dl && !((cd.h - lmn) >= cv.min_prom)) continue;
+            if (dl && !((cd.h - lmn) >= cv.min_prom)) { if (cv.keep_failed && lane == 0) emit(cd.ps, cd.pe, cd.h, failed_prom()); continue; }
             const bool dr = side_scan_wave<1>(win, (int)(cd.pe - w_lo), wn, cd.h, rmn, lane) || w_hi == b;
-            if (dr && !((cd.h - rmn) >= cv.min_prom)) continue;
+            if (dr && !((cd.h - rmn) >= cv.min_prom)) { if (cv.keep_failed && lane == 0) emit(cd.ps, cd.pe, cd.h, failed_prom()); continue; }
             if (dl && dr) {
                 if (lane == 0) emit(cd.ps, cd.pe, cd.h, cd.h - fmaxf(lmn, rmn));
                 continue;
@@ -500,7 +514,7 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
         // stage 3: the walk through global memory
         float prom = 0.0f;
         const bool keep = prominence(cv.g, cv.stats, cv.sp, a, b, cd.ps, cd.pe, cd.h, cv.min_prom, lane, prom);
-        if (keep && lane == 0) emit(cd.ps, cd.pe, cd.h, prom);
+        if (lane == 0 && (keep || cv.keep_failed)) emit(cd.ps, cd.pe, cd.h, keep ? prom : failed_prom());
     }
     __syncthreads();
     if (tid == 0) *queue_n = 0;
@@ -511,8 +525,11 @@ __device__ void scan_piece(const ChunkView& cv, long long lo, long long hi, floa
 // res[]; order them by height descending (ties: position ascending), apply the greedy
 // min_distance filter, write the result header, the chunk's output list and, for lists
 // longer than a header holds, the spill arena.
+// (with PeakPolicy::order == 1 the list also holds the maxima that failed the prominence test: they take part
+// in the distance filter -- a kept one suppresses its lower neighbours -- and are left out of the result)
 __device__ void finish_chunk(am_peak* res, int rn, int* order, int overflow, long long min_dist, float seg_min,
-                             am_peak* my_out, SegHeader* hd, const PeakArena& arena, int* kept_s, int* spill_off_s, int tid) {
+                             am_peak* my_out, SegHeader* hd, const PeakArena& arena, int* kept_s, int* spill_off_s, int tid,
+                             const PeakPolicy& pol) {
     for (int i = tid; i < rn; i += kPeakThreads) {
         const float hi_ = res[i].height; const uint64_t si = res[i].start;
         int rank = 0;
@@ -525,22 +542,24 @@ __device__ void finish_chunk(am_peak* res, int rn, int* order, int overflow, lon
     __syncthreads();
     // ---- min_distance: greedy by descending height (serial, rn is small) ----
     if (tid == 0) {
-        int kept = 0;
+        int kept = 0, nfilt = 0;   // peaks in the result; peaks the distance filter kept (order[0 .. nfilt): nfilt <= r, so the slots are free)
         for (int r = 0; r < rn; ++r) {
-            const am_peak pk = res[order[r]];
-            const long long mid = (long long)((pk.start + pk.end) / 2);
+            const int ir = order[r];
+            const am_peak pk = res[ir];
+            const long long mid = dist_pos(pk, pol.from_start);
             bool ok = true;
             if (min_dist > 0) {
-                for (int k = 0; k < kept && ok; ++k) {
-                    const long long mk = (long long)((my_out[k].start + my_out[k].end) / 2);
+                for (int k = 0; k < nfilt && ok; ++k) {
+                    const long long mk = dist_pos(res[order[k]], pol.from_start);
                     const long long d = mid > mk ? mid - mk : mk - mid;
-                    if (d < min_dist) ok = false;
+                    if (too_close(d, min_dist, pol.inclusive)) ok = false;
                 }
             }
-            if (ok) {
-                if (kept < kInlinePeaks) hd->first[kept] = pk;
-                my_out[kept++] = pk;
-            }
+            if (!ok) continue;
+            order[nfilt++] = ir;
+            if (pol.order && !(pk.prominence == pk.prominence)) continue;   // failed the prominence test (failed_prom)
+            if (kept < kInlinePeaks) hd->first[kept] = pk;
+            my_out[kept++] = pk;
         }
         // a list longer than the header holds goes to the spill arena as a whole
         int off = -1, ovf = overflow;
@@ -657,7 +676,7 @@ __global__ void __launch_bounds__(kPeakThreads)
 peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
              am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide,
-             int only_failed) {
+             int only_failed, PeakPolicy pol) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -837,6 +856,11 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
                             my_out[0] = pk;
                             hdr[blockIdx.x].n = 1; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1;
                             fast_s = 2;
+                        } else if (pol.order) {
+                            // distance filter first: the chunk's highest maximum is its only survivor, and it
+                            // has just failed the prominence test -- the chunk has no peak
+                            hdr[blockIdx.x].n = 0; hdr[blockIdx.x].overflow = 0; hdr[blockIdx.x].seg_min = seg_min; hdr[blockIdx.x].arena_off = -1;
+                            fast_s = 2;
                         } else fast_s = 0;
                     }
                 }
@@ -854,7 +878,8 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     if (has_full) {
         for (long long t = tf + tid; t < tl; t += kPeakThreads) {
             if (!((stats[t].y - seg_min) >= min_prom)) continue;
-            if (staged ? tile_can_qualify(tstats, t, tf, tl, min_prom) : tile_can_qualify(stats + tf, t, tf, tl, min_prom)) {
+            // (the tile-level prominence bound rejects maxima the distance-first order still needs)
+            if (pol.order || (staged ? tile_can_qualify(tstats, t, tf, tl, min_prom) : tile_can_qualify(stats + tf, t, tf, tl, min_prom))) {
                 const int slot = atomicAdd(&cand_n, 1);
                 if (slot < kCandCap) cand_tiles[slot] = (int)(t - tf);
             }
@@ -880,7 +905,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __syncthreads();
     if (tid == 0) {
         int can = (head_hi > a ? 1 : 0) | (b > tail_lo ? 2 : 0);
-        if (has_full) {
+        if (has_full && !pol.order) {
             const float2* tl_stats = staged ? tstats : stats + tf;
             float m = FLT_MAX, M = -FLT_MAX;
             for (int k = 0; k < kWaves; ++k) { m = fminf(m, pmm_s[0][k]); M = fmaxf(M, pmm_s[1][k]); }
@@ -928,7 +953,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     // more candidates than the list holds: visit every full tile instead
     const bool all_tiles = cand_n > kCandCap;
     const long long nmid = has_full ? (all_tiles ? (tl - tf) : cand_n) : 0;
-    ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
+    ChunkView cv{g, stats, sp, a, b, seg_min, min_prom, pol.order};
     const bool best_mode = min_dist >= b - a && b - a < 0xFFFFFFFFll;
     auto emit = [&](long long ps, long long pe, float h, float prom) {
         if (best_mode) { atomicMax(&best_s, best_key(h, ps - a)); return; }
@@ -947,7 +972,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         else {
             const long long t = tf + (all_tiles ? (pc - 1) : (long long)cand_tiles[pc - 1]);
             lo = t * kTile; hi = lo + kTile;
-            if (all_tiles && !((stats[t].y - seg_min) >= min_prom && tile_can_qualify(stats + tf, t, tf, tl, min_prom))) continue;
+            if (all_tiles && !((stats[t].y - seg_min) >= min_prom && (pol.order || tile_can_qualify(stats + tf, t, tf, tl, min_prom)))) continue;
         }
         // (a chunk without a full tile inside has a head piece of up to 2 * kTile - 2 scores:
         // the LDS window holds kTile + halo, so long pieces go in slices)
@@ -959,7 +984,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
         return;
     }
     const int rn = res_n < AM_MAX_PEAKS_PER_CHUNK ? res_n : AM_MAX_PEAKS_PER_CHUNK;
-    finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid);
+    finish_chunk(res, rn, order, overflow, min_dist, seg_min, my_out, &hdr[blockIdx.x], arena, &kept_s, &spill_off_s, tid, pol);
 }
 
 // grid (kWideParts, nsegs): part p of chunk s takes the head piece (p == 0), the tail piece
@@ -967,7 +992,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
 // prominence filter to the chunk's list.
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
-           const Segment* __restrict__ segs, float min_prom, long long min_dist, SparseScores sp, WideState wide) {
+           const Segment* __restrict__ segs, float min_prom, long long min_dist, SparseScores sp, WideState wide, PeakPolicy pol) {
     __shared__ Cand queue[kWideQueue];
     __shared__ int queue_n;
     __shared__ int overflow;
@@ -985,7 +1010,7 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
     const float seg_min = wide.seg_min[seg];
     if (tid == 0) { queue_n = 0; overflow = 0; }
     __syncthreads();
-    ChunkView cv{g, stats, sp, a, b, seg_min, min_prom};
+    ChunkView cv{g, stats, sp, a, b, seg_min, min_prom, pol.order};
     am_peak* list = wide.list + (size_t)seg * wide.cap;
     const bool best_mode = min_dist >= b - a && b - a < 0xFFFFFFFFll;
     auto emit = [&](long long ps, long long pe, float h, float prom) {
@@ -1011,7 +1036,7 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
         }
     } else if (has_full) {
         for (long long t = tf + part; t < tl; t += kWideParts) {
-            if (!((stats[t].y - seg_min) >= min_prom && tile_can_qualify(stats + tf, t, tf, tl, min_prom))) continue;
+            if (!((stats[t].y - seg_min) >= min_prom && (pol.order || tile_can_qualify(stats + tf, t, tf, tl, min_prom)))) continue;
             scan_piece(cv, t * kTile, (t + 1) * kTile, win, wruns, queue, kWideQueue, &queue_n, &overflow, tid, emit);
         }
     }
@@ -1033,7 +1058,7 @@ peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restric
 constexpr int kBigThreads = 256;
 __global__ void __launch_bounds__(kBigThreads)
 peaks_big_finish(const am_peak* __restrict__ list, unsigned n, long long a, long long min_dist,
-                 unsigned long long* keys, unsigned* idx, long long* table, am_peak* __restrict__ out, unsigned* out_n) {
+                 unsigned long long* keys, unsigned* idx, long long* table, am_peak* __restrict__ out, unsigned* out_n, PeakPolicy pol) {
     __shared__ unsigned cnt[16 * kBigThreads];
     __shared__ unsigned part[kBigThreads];
     const int tid = threadIdx.x;
@@ -1083,12 +1108,12 @@ peaks_big_finish(const am_peak* __restrict__ list, unsigned n, long long a, long
         long long mid = 0, bkt = 0;
         if (ok) {
             pk = list[i0[i]];
-            mid = (long long)((pk.start + pk.end) / 2) - a;
+            mid = dist_pos(pk, pol.from_start) - a;
             if (min_dist > 0) {
                 bkt = mid / min_dist;
                 for (long long bb = bkt > 0 ? bkt - 1 : 0; bb <= bkt + 1 && ok; ++bb) {
                     const long long m = __hip_atomic_load(&table[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (m >= 0) { const long long d = mid > m ? mid - m : m - mid; if (d < min_dist) ok = false; }
+                    if (m >= 0) { const long long d = mid > m ? mid - m : m - mid; if (too_close(d, min_dist, pol.inclusive)) ok = false; }
                 }
             }
         }
@@ -1100,15 +1125,15 @@ peaks_big_finish(const am_peak* __restrict__ list, unsigned n, long long a, long
                 const int L = __ffsll((long long)pending) - 1;
                 const long long midL = ((long long)__shfl((int)(mid >> 32), L) << 32) | (unsigned)__shfl((int)(mid & 0xffffffffll), L);
                 if (lane == L) keep = true;
-                if (ok && lane > L) { const long long d = mid > midL ? mid - midL : midL - mid; if (d < min_dist) ok = false; }
+                if (ok && lane > L) { const long long d = mid > midL ? mid - midL : midL - mid; if (too_close(d, min_dist, pol.inclusive)) ok = false; }
                 pending = __ballot(ok && lane > L);
             }
         }
-        const unsigned long long kb = __ballot(keep);
-        if (keep) {
-            out[kept + (unsigned)__popcll(kb & ((1ull << lane) - 1ull))] = pk;
-            if (min_dist > 0) __hip_atomic_store(&table[bkt], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (distance-first order: a kept maximum that failed the prominence test enters the table, not the result)
+        const bool result = keep && !(pol.order && !(pk.prominence == pk.prominence));
+        const unsigned long long kb = __ballot(result);
+        if (result) out[kept + (unsigned)__popcll(kb & ((1ull << lane) - 1ull))] = pk;
+        if (keep && min_dist > 0) __hip_atomic_store(&table[bkt], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         kept += (unsigned)__popcll(kb);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // this step's table entries before the next step's look-ups
     }
@@ -1119,7 +1144,7 @@ peaks_big_finish(const am_peak* __restrict__ list, unsigned n, long long a, long
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_finish(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist, am_peak* __restrict__ out,
-             SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide) {
+             SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide, PeakPolicy pol) {
     __shared__ am_peak res[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int order[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int kept_s, spill_off_s;
@@ -1130,7 +1155,7 @@ peaks_finish(const float* __restrict__ g, long long g_len, const float2* __restr
     const Segment sg = segs[seg];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     if (min_dist >= b - a && b - a < 0xFFFFFFFFll) {
-        ChunkView cv{g, stats, sp, a, b, wide.seg_min[seg], min_prom};
+        ChunkView cv{g, stats, sp, a, b, wide.seg_min[seg], min_prom, pol.order};
         finish_best(cv, wide.best[seg], my_out, &hdr[seg], &pe_s, tid);
         return;
     }
@@ -1140,7 +1165,7 @@ peaks_finish(const float* __restrict__ g, long long g_len, const float2* __restr
     for (int i = tid; i < rn; i += kPeakThreads) res[i] = list[i];
     __syncthreads();
     finish_chunk(res, rn, order, cnt > (unsigned)AM_MAX_PEAKS_PER_CHUNK ? 1 : 0, min_dist, wide.seg_min[seg],
-                 my_out, &hdr[seg], arena, &kept_s, &spill_off_s, tid);
+                 my_out, &hdr[seg], arena, &kept_s, &spill_off_s, tid, pol);
 }
 
 // ---------------------------------------------------------------------------
@@ -1260,16 +1285,16 @@ hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long 
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
-                        const WideState& wide, bool only_failed) {
+                        const WideState& wide, bool only_failed, const PeakPolicy& pol) {
     if (nsegs <= 0) return hipSuccess;
     hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide, only_failed ? 1 : 0);
+                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide, only_failed ? 1 : 0, pol);
     if (wide.list != nullptr) {
         // both return at once for chunks that peaks_kernel finished itself (the usual case)
         hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                           min_prom, min_dist, sp, wide);
+                           min_prom, min_dist, sp, wide, pol);
         hipLaunchKernelGGL(peaks_finish, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs, min_prom, min_dist,
-                           d_out, d_hdr, sp, arena, wide);
+                           d_out, d_hdr, sp, arena, wide, pol);
     }
     return hipGetLastError();
 }
@@ -1281,13 +1306,14 @@ hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment
 }
 
 hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len, const float2* stats, const Segment* d_seg,
-                                 float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide) {
-    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, min_prom, min_dist, sp, wide);
+                                 float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide, const PeakPolicy& pol) {
+    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, min_prom, min_dist, sp, wide, pol);
     return hipGetLastError();
 }
 hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
-                                   unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n) {
-    hipLaunchKernelGGL(peaks_big_finish, dim3(1), dim3(kBigThreads), 0, st, list, n, a, min_dist, keys, idx, table, out, out_n);
+                                   unsigned long long* keys, unsigned* idx, long long* table, am_peak* out, unsigned* out_n,
+                                   const PeakPolicy& pol) {
+    hipLaunchKernelGGL(peaks_big_finish, dim3(1), dim3(kBigThreads), 0, st, list, n, a, min_dist, keys, idx, table, out, out_n, pol);
     return hipGetLastError();
 }
 

@@ -362,6 +362,19 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *   "device_redo" (0/1, default 1): in a batch, chunks whose sparse-score certificate fails get their dense
  *       inverse pass on the device, beside the next haystack's transforms; 0 = the host path does it
  *       after the call's kernels (results are identical; for measurements).
+ *   The rules of the path that no source or test available offline pins (the crates find_peaks 0.1 and common are
+ *   not in the reference tree).  Defaults (0) = the documented choices of oracle/oracle.c; every
+ *   alternative is implemented in the kernels, on the host and in the checker (oracle.h orc_policy), DESIGN.md
+ *   section 3 lists inputs on which they differ -- one run of the crates on those pins each rule:
+ *     "peak_filter_order"  0: find_peaks filters by prominence, then by distance (audio_matcher.rs:226-229 builder order)
+ *                          1: by distance first (every maximum that passes the height test competes), then by prominence:
+ *                             scipy.signal.find_peaks' order
+ *     "distance_rule"      bit 0: the distance filter drops a peak at a distance  0: <  1: <=  min_distance from a kept, higher one
+ *                          bit 1: measured between  0: plateau middles (start + end) / 2   1: plateau starts
+ *     "tail_window"        0: chunked(chunk + overlap, hop = chunk) (audio_matcher.rs:104) yields the shorter windows at the
+ *                             end of the haystack   1: full-length windows only
+ *     "surrounding_from"   filter_surrounding (audio_matcher.rs:136-139): 0: both neighbours from the sorted, unfiltered
+ *                             sequence   1: the neighbour before = the last element kept (a sequential filter)
  *   test hooks: "debug_no_realloc" (0/1): a scratch buffer that would have to be (re)allocated while a batch
  *       is being queued fails the call with AM_ERR_HIP instead (every such buffer is sized before the queueing
  *       loop; this makes a violation visible); "debug_redo_arm_at" (k >= 0: the device-side redo of a batch is

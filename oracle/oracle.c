@@ -131,7 +131,14 @@ size_t orc_correlate(const float* within, size_t w, const float* needle, size_t 
  *   5. result ordered by height descending (K2 order: 3, 5, 1).
  * Filter order 3 -> 4 is a choice [PARITY UNPINNED]; with the reference's
  * default min_distance (480 s * sr > chunk length) at most one peak per chunk
- * survives either way. */
+ * survives either way -- but WHICH one, or none, differs when the chunk's
+ * tallest maximum fails the prominence bound (scipy filters by distance first:
+ * the tallest maximum suppresses every other one and is then dropped itself).
+ *
+ * Every unpinned rule is a field of orc_policy (oracle.h); the defaults are the
+ * choices above, the alternatives are restated here and implemented in the
+ * library as options of the same names, so that one run by someone who has the
+ * crate pins each of them. */
 typedef struct { size_t start, end; float height, prom; } pk_t;
 
 static int cmp_height_desc(const void* a, const void* b) {
@@ -141,8 +148,17 @@ static int cmp_height_desc(const void* a, const void* b) {
     return x->start < y->start ? -1 : (x->start > y->start ? 1 : 0);
 }
 
+static size_t dist_pos(const pk_t* p, int from_start) { return from_start ? p->start : (p->start + p->end) / 2; }
+
 size_t orc_find_peaks(const float* y, size_t n, float min_prominence, size_t min_distance,
                       orc_peak* out, size_t cap) {
+    return orc_find_peaks_policy(y, n, min_prominence, min_distance, NULL, out, cap);
+}
+
+size_t orc_find_peaks_policy(const float* y, size_t n, float min_prominence, size_t min_distance,
+                             const orc_policy* pol, orc_peak* out, size_t cap) {
+    const int order = pol ? pol->peak_filter_order : 0;
+    const int inclusive = pol ? (pol->distance_rule & 1) : 0, from_start = pol ? ((pol->distance_rule >> 1) & 1) : 0;
     if (n < 3) return 0;
     size_t cnt = 0, alloc = 64;
     pk_t* pk = (pk_t*)malloc(sizeof(pk_t) * alloc);
@@ -175,22 +191,37 @@ size_t orc_find_peaks(const float* y, size_t n, float min_prominence, size_t min
         for (size_t k = pk[p].end; k < n; ++k) { if (y[k] > h) break; if (y[k] < rmin) rmin = y[k]; }
         float base = lmin > rmin ? lmin : rmin;
         pk[p].prom = h - base;
-        if (pk[p].prom >= min_prominence) pk[kept++] = pk[p];
+        /* order 0: the prominence filter runs first; order 1: every maximum goes into the distance filter */
+        if (order || pk[p].prom >= min_prominence) pk[kept++] = pk[p];
     }
     cnt = kept;
     qsort(pk, cnt, sizeof(pk_t), cmp_height_desc);
     if (min_distance > 0) {
+        /* greedy by descending height; the kept list of an order-1 run is quadratic in the number of maxima
+         * at worst -- a bucket table (one kept peak per min_distance-wide bucket at most) keeps it linear */
+        size_t nb = n / min_distance + 3;
+        long long* table = (long long*)malloc(sizeof(long long) * nb);
+        if (!table) { free(pk); return 0; }
+        for (size_t b = 0; b < nb; ++b) table[b] = -1;
         kept = 0;
         for (size_t p = 0; p < cnt; ++p) {
-            size_t mid = (pk[p].start + pk[p].end) / 2;
+            size_t mid = dist_pos(&pk[p], from_start);
+            size_t bkt = mid / min_distance;
             int ok = 1;
-            for (size_t q = 0; q < kept && ok; ++q) {
-                size_t mq = (pk[q].start + pk[q].end) / 2;
+            for (size_t b = bkt > 0 ? bkt - 1 : 0; b <= bkt + 1 && ok; ++b) {
+                if (table[b] < 0) continue;
+                size_t mq = (size_t)table[b];
                 size_t d = mid > mq ? mid - mq : mq - mid;
-                if (d < min_distance) ok = 0;
+                if (inclusive ? d <= min_distance : d < min_distance) ok = 0;
             }
-            if (ok) pk[kept++] = pk[p];
+            if (ok) { table[bkt] = (long long)mid; pk[kept++] = pk[p]; }
         }
+        free(table);
+        cnt = kept;
+    }
+    if (order) {   /* ... and the prominence filter afterwards */
+        kept = 0;
+        for (size_t p = 0; p < cnt; ++p) if (pk[p].prom >= min_prominence) pk[kept++] = pk[p];
         cnt = kept;
     }
     for (size_t p = 0; p < cnt && p < cap; ++p) {
@@ -244,6 +275,7 @@ typedef struct {
     const float* hay; size_t h; const float* needle; size_t s;
     size_t chunk, window; float min_prom; size_t min_dist;
     int scale, policy, prec;
+    const orc_policy* pol;
     size_t n_windows;
     const void* spec; size_t spec_pad;   /* cached needle spectrum (ORC_FFT_POW2_CACHED) */
     size_t next;                 /* work counter (par_bridge analogue) */
@@ -263,6 +295,7 @@ static void* cc_worker(void* arg) {
         size_t w = J->h - off < J->window ? J->h - off : J->window; /* tail window */
         J->per_window[i] = NULL; J->per_window_n[i] = 0;
         if (w < J->s) continue; /* no valid lag; see note in orc_calc_chunks */
+        if (J->pol && J->pol->tail_window && w < J->window) continue; /* policy: full-length windows only */
         size_t v = w - J->s + 1;
         float* sc = (float*)malloc(sizeof(float) * v);
         if (!sc) { J->failed = 1; continue; }
@@ -270,10 +303,10 @@ static void* cc_worker(void* arg) {
                            J->policy, J->prec, sc, v, J->spec, J->spec_pad) != v) { J->failed = 1; free(sc); continue; } /* :120-122 */
         size_t cap = 16, n;
         orc_peak* pk = (orc_peak*)malloc(sizeof(orc_peak) * cap);
-        n = orc_find_peaks(sc, v, J->min_prom, J->min_dist, pk, cap);                     /* :124 */
+        n = orc_find_peaks_policy(sc, v, J->min_prom, J->min_dist, J->pol, pk, cap);       /* :124 */
         if (n > cap) {
             cap = n; free(pk); pk = (orc_peak*)malloc(sizeof(orc_peak) * cap);
-            n = orc_find_peaks(sc, v, J->min_prom, J->min_dist, pk, cap);
+            n = orc_find_peaks_policy(sc, v, J->min_prom, J->min_dist, J->pol, pk, cap);
         }
         for (size_t p = 0; p < n; ++p) { pk[p].start += off; pk[p].end += off; }           /* :126, lib.rs:8-10 */
         J->per_window[i] = pk; J->per_window_n[i] = n;
@@ -304,8 +337,19 @@ size_t orc_calc_chunks(uint32_t sr, const float* haystack, size_t h,
                        float min_prominence, size_t min_distance, double overshadow_distance_s,
                        int scale, int fft_policy, int precision, int threads,
                        orc_peak* out, size_t cap) {
+    return orc_calc_chunks_policy(sr, haystack, h, needle, s, chunk, overlap, min_prominence, min_distance,
+                                  overshadow_distance_s, scale, fft_policy, precision, threads, NULL, out, cap);
+}
+
+size_t orc_calc_chunks_policy(uint32_t sr, const float* haystack, size_t h,
+                              const float* needle, size_t s,
+                              size_t chunk, size_t overlap,
+                              float min_prominence, size_t min_distance, double overshadow_distance_s,
+                              int scale, int fft_policy, int precision, int threads, const orc_policy* pol,
+                              orc_peak* out, size_t cap) {
     if (chunk == 0 || h == 0 || s == 0) return 0;
     cc_job J; memset(&J, 0, sizeof(J));
+    J.pol = pol;
     J.hay = haystack; J.h = h; J.needle = needle; J.s = s;
     J.chunk = chunk; J.window = chunk + overlap; J.min_prom = min_prominence; J.min_dist = min_distance;
     J.scale = scale; J.policy = fft_policy; J.prec = precision;
@@ -363,12 +407,17 @@ size_t orc_calc_chunks(uint32_t sr, const float* haystack, size_t h,
         free(tmp);
     }
     size_t n_out = 0;
+    const int from_filtered = pol ? pol->surrounding_from : 0;
+    orc_peak last_kept; int have_kept = 0;
+    memset(&last_kept, 0, sizeof(last_kept));
     for (size_t i = 0; i < total; ++i) {
-        const orc_peak* before = i > 0 ? &all[i - 1] : NULL;
+        /* policy surrounding_from = 1: the neighbour before is the last element that was kept */
+        const orc_peak* before = from_filtered ? (have_kept ? &last_kept : NULL) : (i > 0 ? &all[i - 1] : NULL);
         const orc_peak* after = i + 1 < total ? &all[i + 1] : NULL;
         if (orc_is_overshadowed(&all[i], before, sr, overshadow_distance_s) ||
             orc_is_overshadowed(&all[i], after, sr, overshadow_distance_s))
             continue;
+        last_kept = all[i]; have_kept = 1;
         if (n_out < cap) out[n_out] = all[i];
         ++n_out;
     }

@@ -70,6 +70,22 @@ typedef struct {
     float prominence;
 } orc_peak;
 
+/* The rules no source or test available offline pins (find_peaks 0.1 and common are absent from the reference
+ * tree).  A zeroed struct (or NULL) = the documented defaults; every alternative is restated in
+ * oracle.c and implemented in the library as the option of the same name (am_set_option).
+ *   peak_filter_order  0: prominence filter, then distance filter       1: distance first, then prominence (scipy's order)
+ *   distance_rule      bit 0 -- a peak is dropped at a distance  0: < min_distance   1: <= min_distance  from a kept, higher one
+ *                      bit 1 -- measured between                0: plateau middles  1: plateau starts
+ *   tail_window        0: chunked() emits the shorter windows at the end of the haystack   1: full-length windows only
+ *   surrounding_from   filter_surrounding's neighbours: 0: both from the sorted, unfiltered sequence
+ *                                                       1: the one before = the last element kept (sequential filter) */
+typedef struct {
+    int peak_filter_order;
+    int distance_rule;
+    int tail_window;
+    int surrounding_from;
+} orc_policy;
+
 /* mp3_reader.rs:28-37: mono = (l as f32 + r as f32) * 0.5 * PCM_FACTOR,
  * PCM_FACTOR = 1.0 / 65535 as f32 (mp3_reader.rs:12). */
 void orc_pcm_s16_stereo_to_mono(const int16_t* interleaved_lr, size_t frames, float* out);
@@ -96,6 +112,9 @@ size_t orc_correlate(const float* within, size_t w, const float* needle, size_t 
 size_t orc_find_peaks(const float* y, size_t n, float min_prominence, size_t min_distance,
                       orc_peak* out, size_t cap);
 
+size_t orc_find_peaks_policy(const float* y, size_t n, float min_prominence, size_t min_distance,
+                             const orc_policy* pol, orc_peak* out, size_t cap);
+
 /* is_overshadowed (audio_matcher.rs:143-160); other == NULL is Option::None */
 int orc_is_overshadowed(const orc_peak* element, const orc_peak* other, uint32_t sr,
                         double max_distance_s);
@@ -111,6 +130,13 @@ size_t orc_calc_chunks(uint32_t sr, const float* haystack, size_t h,
                        float min_prominence, size_t min_distance, double overshadow_distance_s,
                        int scale, int fft_policy, int precision, int threads,
                        orc_peak* out, size_t cap);
+
+size_t orc_calc_chunks_policy(uint32_t sr, const float* haystack, size_t h,
+                              const float* needle, size_t s,
+                              size_t chunk, size_t overlap,
+                              float min_prominence, size_t min_distance, double overshadow_distance_s,
+                              int scale, int fft_policy, int precision, int threads, const orc_policy* pol,
+                              orc_peak* out, size_t cap);
 
 /* (secs * sr).round() as usize : audio_matcher.rs:99-100 */
 size_t orc_round_samples(double seconds, uint32_t sr);

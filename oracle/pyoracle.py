@@ -28,6 +28,16 @@ class OrcPeak(C.Structure):
         return (int(self.start), int(self.end), float(self.height), float(self.prominence))
 
 
+class OrcPolicy(C.Structure):
+    """oracle.h orc_policy: the unpinned rules as switches (all zero = the defaults)."""
+    _fields_ = [("peak_filter_order", C.c_int), ("distance_rule", C.c_int), ("tail_window", C.c_int),
+                ("surrounding_from", C.c_int)]
+
+
+def policy(peak_filter_order=0, distance_rule=0, tail_window=0, surrounding_from=0) -> OrcPolicy:
+    return OrcPolicy(int(peak_filter_order), int(distance_rule), int(tail_window), int(surrounding_from))
+
+
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc if missing or stale."""
     srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "oracle.h", "fft_impl.inc")]
@@ -62,6 +72,14 @@ def lib():
         L.orc_find_peaks.argtypes = [f32p, C.c_size_t, C.c_float, C.c_size_t,
                                      C.POINTER(OrcPeak), C.c_size_t]
         L.orc_find_peaks.restype = C.c_size_t
+        L.orc_find_peaks_policy.argtypes = [f32p, C.c_size_t, C.c_float, C.c_size_t, C.POINTER(OrcPolicy),
+                                            C.POINTER(OrcPeak), C.c_size_t]
+        L.orc_find_peaks_policy.restype = C.c_size_t
+        L.orc_calc_chunks_policy.argtypes = [C.c_uint32, f32p, C.c_size_t, f32p, C.c_size_t,
+                                             C.c_size_t, C.c_size_t, C.c_float, C.c_size_t, C.c_double,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OrcPolicy),
+                                             C.POINTER(OrcPeak), C.c_size_t]
+        L.orc_calc_chunks_policy.restype = C.c_size_t
         L.orc_is_overshadowed.argtypes = [C.POINTER(OrcPeak), C.POINTER(OrcPeak), C.c_uint32, C.c_double]
         L.orc_is_overshadowed.restype = C.c_int
         L.orc_calc_chunks.argtypes = [C.c_uint32, f32p, C.c_size_t, f32p, C.c_size_t,
@@ -114,11 +132,12 @@ def correlate(within, needle, mode=MODE_VALID, scale=SCALE_NONE, fft=FFT_POW2, p
     return out
 
 
-def find_peaks(y, min_prominence=0.0, min_distance=0, cap=None):
+def find_peaks(y, min_prominence=0.0, min_distance=0, cap=None, pol: OrcPolicy | None = None):
     a, ap = _f32(y)
     cap = cap or max(16, a.size)
     buf = (OrcPeak * cap)()
-    n = lib().orc_find_peaks(ap, a.size, float(min_prominence), int(min_distance), buf, cap)
+    n = lib().orc_find_peaks_policy(ap, a.size, float(min_prominence), int(min_distance),
+                                    C.byref(pol) if pol is not None else None, buf, cap)
     return [buf[i].as_tuple() for i in range(min(n, cap))]
 
 
@@ -131,13 +150,14 @@ def is_overshadowed(element, other, sr, max_distance_s) -> bool:
 
 def calc_chunks(sr, haystack, needle, chunk, overlap, min_prominence, min_distance,
                 overshadow_distance_s, scale=SCALE_LIB, fft=FFT_POW2, prec=PREC_F64,
-                threads=1, cap=4096):
+                threads=1, cap=4096, pol: OrcPolicy | None = None):
     h, hp = _f32(haystack)
     n, np_ = _f32(needle)
     buf = (OrcPeak * cap)()
-    cnt = lib().orc_calc_chunks(sr, hp, h.size, np_, n.size, chunk, overlap,
-                                float(min_prominence), int(min_distance),
-                                float(overshadow_distance_s), scale, fft, prec, threads, buf, cap)
+    cnt = lib().orc_calc_chunks_policy(sr, hp, h.size, np_, n.size, chunk, overlap,
+                                       float(min_prominence), int(min_distance),
+                                       float(overshadow_distance_s), scale, fft, prec, threads,
+                                       C.byref(pol) if pol is not None else None, buf, cap)
     if cnt == C.c_size_t(-1).value:
         raise RuntimeError("orc_calc_chunks failed")
     return [buf[i].as_tuple() for i in range(min(cnt, cap))]
