@@ -364,7 +364,7 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *       after the call's kernels (results are identical; for measurements).
  *   The rules of the path that no source or test available offline pins (the crates find_peaks 0.1 and common are
  *   not in the reference tree).  Defaults (0) = the documented choices of oracle/oracle.c; every
- *   alternative is implemented in the kernels, on the host and in the checker (oracle.h orc_policy), DESIGN.md
+ *   alternative is implemented in the kernels, on the host and in the test checker (same switches), DESIGN.md
  *   section 3 lists inputs on which they differ -- one run of the crates on those pins each rule:
  *     "peak_filter_order"  0: find_peaks filters by prominence, then by distance (audio_matcher.rs:226-229 builder order)
  *                          1: by distance first (every maximum that passes the height test competes), then by prominence:
