@@ -97,6 +97,21 @@ def build_cli(force: bool = False) -> str:
     return CLI
 
 
+PUSHBENCH = os.path.join(HERE, "bin", "pushbench")
+
+
+def build_pushbench(force: bool = False) -> str:
+    """host/pushbench.cpp: what feeding the library from host memory costs (C ABI only)."""
+    lib = build_library()
+    src = os.path.join(HOST, "pushbench.cpp")
+    if not force and not _stale(PUSHBENCH, [src, lib]):
+        return PUSHBENCH
+    os.makedirs(os.path.dirname(PUSHBENCH), exist_ok=True)
+    subprocess.check_call([_hipcc(), "-O2", "-std=c++17", "-x", "c++", src, "-o", PUSHBENCH,
+                           f"-L{HERE}", "-laudiomatch_amd", "-Wl,-rpath,$ORIGIN/.."])
+    return PUSHBENCH
+
+
 def build_selftest() -> str:
     """CPU-only self test of the host-side rows (g++ only)."""
     out = os.path.join(OBJ, "am_host_selftest")
@@ -110,3 +125,4 @@ def build_selftest() -> str:
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv))
+    print(build_pushbench(force="--force" in sys.argv))

@@ -1748,9 +1748,21 @@ struct am_stream {
     int fmt = AM_FMT_F32_MONO;
     am_match_params p{};
     am::DevBuf hay, scores, stats32, side;
-    size_t cap = 0, len = 0;          // elements (f32 samples or stereo frames, 4 bytes each)
+    size_t cap = 0, len = 0;          // elements (f32 samples or stereo frames, 4 bytes each); len = accepted so far
+    size_t sent = 0;                  // elements whose host-to-device copy has been issued (len - sent sit in the staging ring)
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied = nullptr;
+    // Two-slot staging ring in pinned host memory: a push of a decoder-sized piece (minimp3 yields 1152 frames,
+    // mp3_reader.rs:28-37) is a host memcpy into the current slot and returns; a full slot goes to the device as one
+    // asynchronous copy while the other slot fills.  Large pushes bypass the ring (one copy straight from the caller's
+    // buffer, at link speed when that buffer is pinned: am_host_alloc / am_host_register).
+    static constexpr size_t kStageElems = (size_t)1 << 20;    // 4 MB per slot
+    static constexpr size_t kDirectElems = (size_t)1 << 18;   // pushes of 1 MB and more are copied directly
+    am::HostBuf stage[2];
+    hipEvent_t staged[2] = {nullptr, nullptr};                 // the slot's last copy has left it
+    bool stage_busy[2] = {false, false};
+    int cur = 0;
+    size_t fill = 0;                  // elements in the current slot
     bool early = false;               // block pairs may be launched before the length is known
     long long pairs_done = 0;
     am::Geometry geo{};               // the provisional block layout (from the capacity)
@@ -2020,7 +2032,9 @@ int am_match_stream_begin(const am_needle* hc, int sample_format, size_t expecte
     am_stream* st = new am_stream();
     st->h = h; st->fmt = sample_format; st->p = *p;
     if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&st->copied, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&st->copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&st->staged[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&st->staged[1], hipEventDisableTiming) != hipSuccess) {
         am_match_stream_destroy(st);
         return fail(AM_ERR_HIP, "hipStreamCreate(stream ingest)");
     }
@@ -2031,6 +2045,64 @@ int am_match_stream_begin(const am_needle* hc, int sample_format, size_t expecte
         if ((rc = st->hay.ensure(st->cap * 4)) || (rc = stream_layout(st))) { const std::string keep = t_err; am_match_stream_destroy(st); t_err = keep; return rc; }
     }
     *out = st;
+    return AM_OK;
+}
+
+// the current staging slot goes to the device (asynchronously); the other slot becomes current
+static int stream_flush_slot(am_stream* st) {
+    if (st->fill == 0) return AM_OK;
+    const int b = st->cur;
+    hipError_t e = hipMemcpyAsync(static_cast<char*>(st->hay.p) + st->sent * 4, st->stage[b].p, st->fill * 4, hipMemcpyHostToDevice, st->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(st->staged[b], st->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(st->copied, st->copy_stream);
+    if (e != hipSuccess) { st->failed = true; return hip_fail(e, "stream ingest: copy"); }
+    st->stage_busy[b] = true;
+    st->sent += st->fill;
+    st->fill = 0;
+    st->cur = b ^ 1;
+    return AM_OK;
+}
+
+// K1 / K2 / K3 for every block pair whose samples are on their way to the device (st->sent)
+static int stream_launch_ready_pairs(am_stream* st) {
+    if (!st->early) return AM_OK;
+    am_needle* h = st->h;
+    Ctx* c = h->ctx;
+    // pairs whose two blocks lie completely inside what has arrived: K1 reads [2q hop, (2q + 1) hop + N)
+    const Geometry& g = st->geo;
+    const long long have = (long long)st->sent;
+    long long ready = have >= g.hop + g.N ? ((have - g.N) / g.hop - 1) / 2 + 1 : 0;
+    ready = std::min(ready, g.npairs);
+    if (ready - st->pairs_done < 1) return AM_OK;
+    const Opts o = snapshot_opts(h);
+    Geometry now{};
+    int rc = plan_geometry(h->n, (long long)(st->cap - h->n + 1), o, &now);
+    if (rc) return rc;
+    if (now.logN != g.logN || now.hop != g.hop) {   // an option changed under the stream: start over at finish
+        st->early = false; st->pairs_done = 0;
+        return AM_OK;
+    }
+    ScanRequest scan{};
+    scan.margin = (!o.dense && st->p.min_prominence > 0.f) ? 0.5f * st->p.min_prominence : -1.0f;
+    scan.hist_min = h->hist_min(st->p.scale == AM_SCALE_LIB ? 1 : 0);
+    scan.seg_c = (long long)st->p.chunk;
+    scan.seg_d = (long long)(st->p.chunk + st->p.overlap) - (long long)h->n;
+    if (st->pairs_done > 0 && scan.margin != st->margin) {
+        // "dense_scores" changed between two pushes: the early pairs were written under another rule than the
+        // rest would be -- start over at finish
+        st->early = false; st->pairs_done = 0;
+        return AM_OK;
+    }
+    st->margin = scan.margin;
+    scan.ext_stats32 = &st->stats32; scan.ext_side = &st->side;
+    scan.side_nblocks = g.nblocks;
+    scan.range_a = st->pairs_done * 2 * g.hop;
+    scan.range_b = ready * 2 * g.hop;
+    AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));   // the kernels read what has been copied so far
+    rc = run_correlation(h, o, st->hay.p, (long long)st->cap, 0, (float*)st->scores.p, (long long)(st->cap - h->n + 1),
+                         scale_factor(h, st->p.scale, 1), &scan, st->fmt);
+    if (rc) { st->failed = true; return rc; }
+    st->pairs_done = ready;
     return AM_OK;
 }
 
@@ -2050,7 +2122,7 @@ int am_match_stream_push(am_stream* st, const void* samples, size_t n) {
         DevBuf bigger;
         if ((rc = bigger.ensure(want * 4))) { st->failed = true; return rc; }
         hipError_t e = hipStreamSynchronize(st->copy_stream);
-        if (e == hipSuccess && st->len) e = copy_on_stream(c, bigger.p, st->hay.p, st->len * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && st->sent) e = copy_on_stream(c, bigger.p, st->hay.p, st->sent * 4, hipMemcpyDeviceToDevice);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { bigger.release(); st->failed = true; return hip_fail(e, "stream ingest: grow"); }
         st->hay.release();
@@ -2058,50 +2130,42 @@ int am_match_stream_push(am_stream* st, const void* samples, size_t n) {
         st->cap = want;
         if ((rc = stream_layout(st))) { st->failed = true; return rc; }
     }
-    hipError_t e = hipMemcpyAsync(static_cast<char*>(st->hay.p) + st->len * 4, samples, n * 4, hipMemcpyHostToDevice, st->copy_stream);
-    if (e == hipSuccess) e = hipEventRecord(st->copied, st->copy_stream);
-    if (e != hipSuccess) { st->failed = true; return hip_fail(e, "stream ingest: copy"); }
-    st->len += n;
-    if (!st->early) { AM_HIP(hipStreamSynchronize(st->copy_stream)); return AM_OK; }
-    // pairs whose two blocks lie completely inside what has arrived: K1 reads [2q hop, (2q + 1) hop + N)
-    const Geometry& g = st->geo;
-    const long long have = (long long)st->len;
-    long long ready = have >= g.hop + g.N ? ((have - g.N) / g.hop - 1) / 2 + 1 : 0;
-    ready = std::min(ready, g.npairs);
-    if (ready - st->pairs_done < 1) { AM_HIP(hipStreamSynchronize(st->copy_stream)); return AM_OK; }
-    const Opts o = snapshot_opts(h);
-    Geometry now{};
-    if ((rc = plan_geometry(h->n, (long long)(st->cap - h->n + 1), o, &now))) return rc;
-    if (now.logN != g.logN || now.hop != g.hop) {   // an option changed under the stream: start over at finish
-        st->early = false; st->pairs_done = 0;
+    if (n >= am_stream::kDirectElems) {
+        // a large piece: what the ring holds goes first (order), then one copy straight from the caller's buffer;
+        // the caller may reuse `samples` as soon as this returns, so that copy is waited for
+        if ((rc = stream_flush_slot(st))) return rc;
+        hipError_t e = hipMemcpyAsync(static_cast<char*>(st->hay.p) + st->sent * 4, samples, n * 4, hipMemcpyHostToDevice, st->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(st->copied, st->copy_stream);
+        if (e != hipSuccess) { st->failed = true; return hip_fail(e, "stream ingest: copy"); }
+        st->sent += n;
+        st->len += n;
+        rc = stream_launch_ready_pairs(st);
         AM_HIP(hipStreamSynchronize(st->copy_stream));
-        return AM_OK;
+        return rc;
     }
-    ScanRequest scan{};
-    scan.margin = (!o.dense && st->p.min_prominence > 0.f) ? 0.5f * st->p.min_prominence : -1.0f;
-    scan.hist_min = h->hist_min(st->p.scale == AM_SCALE_LIB ? 1 : 0);
-    scan.seg_c = (long long)st->p.chunk;
-    scan.seg_d = (long long)(st->p.chunk + st->p.overlap) - (long long)h->n;
-    if (st->pairs_done > 0 && scan.margin != st->margin) {
-        // "dense_scores" changed between two pushes: the early pairs were written under another rule than the
-        // rest would be -- start over at finish
-        st->early = false; st->pairs_done = 0;
-        AM_HIP(hipStreamSynchronize(st->copy_stream));
-        return AM_OK;
+    // a small piece: a host memcpy into the staging ring; full slots leave asynchronously
+    const char* src = static_cast<const char*>(samples);
+    size_t left = n;
+    bool flushed = false;
+    while (left) {
+        const int b = st->cur;
+        if (st->fill == 0) {
+            if (!st->stage[b].p && (rc = st->stage[b].ensure(am_stream::kStageElems * 4))) { st->failed = true; return rc; }
+            if (st->stage_busy[b]) {   // (the copy that last left this slot: two slots ago)
+                AM_HIP(hipEventSynchronize(st->staged[b]));
+                st->stage_busy[b] = false;
+            }
+        }
+        const size_t take = std::min(left, am_stream::kStageElems - st->fill);
+        memcpy(static_cast<char*>(st->stage[b].p) + st->fill * 4, src, take * 4);
+        st->fill += take; st->len += take;
+        src += take * 4; left -= take;
+        if (st->fill == am_stream::kStageElems) {
+            if ((rc = stream_flush_slot(st))) return rc;
+            flushed = true;
+        }
     }
-    st->margin = scan.margin;
-    scan.ext_stats32 = &st->stats32; scan.ext_side = &st->side;
-    scan.side_nblocks = g.nblocks;
-    scan.range_a = st->pairs_done * 2 * g.hop;
-    scan.range_b = ready * 2 * g.hop;
-    AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));   // the kernels read what this push has copied
-    rc = run_correlation(h, o, st->hay.p, (long long)st->cap, 0, (float*)st->scores.p, (long long)(st->cap - h->n + 1),
-                         scale_factor(h, st->p.scale, 1), &scan, st->fmt);
-    if (rc) { st->failed = true; return rc; }
-    st->pairs_done = ready;
-    // the caller may reuse `samples` as soon as this returns
-    AM_HIP(hipStreamSynchronize(st->copy_stream));
-    return AM_OK;
+    return flushed ? stream_launch_ready_pairs(st) : AM_OK;
 }
 
 int am_match_stream_finish(am_stream* st, am_peak* out, size_t cap, size_t* n_out) {
@@ -2116,6 +2180,7 @@ int am_match_stream_finish(am_stream* st, am_peak* out, size_t cap, size_t* n_ou
     const size_t len = st->len;
     rc = AM_OK;
     if (len) {
+        if ((rc = stream_flush_slot(st))) return rc;          // what the staging ring still holds
         AM_HIP(hipStreamWaitEvent(c->stream, st->copied, 0));
         const void* src = st->hay.p;
         StreamPre pre{(float*)st->scores.p, &st->stats32, &st->side, st->pairs_done, st->geo.nblocks};
@@ -2136,7 +2201,7 @@ int am_match_stream_finish(am_stream* st, am_peak* out, size_t cap, size_t* n_ou
     }
     // ready for the next file of the same (announced) size; a stream that had to give up its early pairs (an
     // option changed under it) starts afresh
-    st->len = 0; st->pairs_done = 0;
+    st->len = 0; st->sent = 0; st->pairs_done = 0;
     if (!st->early && st->cap) (void)stream_layout(st);
     return rc;
 }
@@ -2151,6 +2216,10 @@ void am_match_stream_destroy(am_stream* st) {
         st->hay.release(); st->scores.release(); st->stats32.release(); st->side.release();
     }
     if (st->copied) (void)hipEventDestroy(st->copied);
+    for (int b = 0; b < 2; ++b) {
+        if (st->staged[b]) (void)hipEventDestroy(st->staged[b]);
+        if (st->stage[b].p) (void)hipHostFree(st->stage[b].p);
+    }
     if (st->copy_stream) (void)hipStreamDestroy(st->copy_stream);
     delete st;
 }
@@ -2275,6 +2344,33 @@ int am_device_free(int device, void* p) {
     if (p) AM_HIP(hipFree(p));
     return AM_OK;
 }
+// Pinned host memory for the buffers a host hands to am_match / am_match_stream_push / am_pool_match_*: the
+// copy engines read it directly (no bounce buffer in the runtime, no page faults), which is what lets N copier
+// threads feed N devices side by side.  Portable: usable from every device's context.
+int am_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(AM_ERR_INVALID_ARG, "bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AM_ERR_NO_DEVICE, "no HIP device available");
+    AM_HIP(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return AM_OK;
+}
+int am_host_free(void* p) {
+    if (p) AM_HIP(hipHostFree(p));
+    return AM_OK;
+}
+int am_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) return fail(AM_ERR_INVALID_ARG, "bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AM_ERR_NO_DEVICE, "no HIP device available");
+    AM_HIP(hipHostRegister(p, bytes, hipHostRegisterPortable));
+    return AM_OK;
+}
+int am_host_unregister(void* p) {
+    if (!p) return fail(AM_ERR_INVALID_ARG, "null pointer");
+    AM_HIP(hipHostUnregister(p));
+    return AM_OK;
+}
+
 int am_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes) {
     Ctx* c = nullptr;
     int rc = get_ctx(device, &c);

@@ -105,6 +105,10 @@ _SIGNATURES = {
     "am_pcm_s16_stereo_to_mono_device": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "am_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
     "am_device_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "am_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "am_host_free": (C.c_int, [C.c_void_p]),
+    "am_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "am_host_unregister": (C.c_int, [C.c_void_p]),
     "am_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "am_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]),
     "am_device_synchronize": (C.c_int, [C.c_int]),
@@ -250,6 +254,43 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class PinnedArray:
+    """A numpy array in pinned host memory (am_host_alloc): what a decoder would write its output into."""
+
+    def __init__(self, shape, dtype):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(lib().am_host_alloc(max(self.nbytes, 4), C.byref(p)))
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().am_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class registered:
+    """with registered(array): the array's memory is pinned for the duration (am_host_register)."""
+
+    def __init__(self, a: np.ndarray):
+        self.a = a
+
+    def __enter__(self):
+        _check(lib().am_host_register(self.a.ctypes.data, self.a.nbytes))
+        return self.a
+
+    def __exit__(self, *exc):
+        _check(lib().am_host_unregister(self.a.ctypes.data))
 
 
 def synth_uniform_device(device: int, n: int, seed: int, stream: int, first: int = 0,

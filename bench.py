@@ -316,6 +316,9 @@ def parse_args():
     ap.add_argument("--total-haystacks", type=int, default=0,
                     help="strong scaling: a step is this many haystacks in total, haystack k on rank k mod N "
                          "(the north-star batch is 1000)")
+    ap.add_argument("--long-haystack", type=float, default=0.0, metavar="HOURS",
+                    help="strong scaling on ONE haystack of this many hours (SURVEY.md 8e, second sentence): rank r matches the "
+                         "window range am_long_plan gives it (am_match_part_device), rank 0 merges (am_merge_peaks); config 2 only")
     ap.add_argument("--no-batch-1000", action="store_true", help="skip the extra 1000-haystack strong-scaling leg")
     ap.add_argument("--dry-shard", action="store_true",
                     help="print every rank's shard of --total-haystacks (default 1000) and stop before any GPU work")
@@ -436,6 +439,48 @@ def strong_batch(am, R, W, total, steps, ranks_per_device=1):
     return local, n_buf
 
 
+def long_haystack_leg(am, R, W, hours, steps, warmup):
+    """ONE haystack of `hours` hours over all ranks (audio_matcher.rs:104-140 with the windows fanned out over GPUs
+    instead of threads): rank r generates the samples of its part on its device (untimed), then per step: every rank
+    matches its windows (am_match_part_device), the unmerged peaks are gathered on the host, rank 0 runs the one
+    sort + overshadow pass (am_merge_peaks).  Returns (seconds per step: max over ranks incl. gather and merge,
+    offsets_ok, part description)."""
+    device = W.device
+    sr, s = W.sr, W.s
+    n = int(hours * 3600 * sr)
+    w0, nw, a, cnt = am.long_plan(n, s, W.params, R.world, R.rank)
+    plants = [600 * sr * m + 30 * sr + 1234 for m in range(int(hours * 6)) if 600 * sr * m + 30 * sr + 1234 + s <= n]
+    buf = am.DeviceBuffer(device, 4 * max(cnt, 1))
+    if cnt:
+        am._check(am.lib().am_synth_uniform_device(device, buf.ptr, 1, 1, a, cnt, 0.25))
+        for t in plants:                       # the part of every planted needle that falls into this rank's samples
+            lo, hi = max(t, a), min(t + s, a + cnt)
+            if lo < hi:
+                am._check(am.lib().am_axpy_device(device, buf.ptr + 4 * (lo - a), W.needle.ptr + 4 * (lo - t), hi - lo, 1.0))
+
+    def step():
+        raw = am.match_part_device(W.algo, buf.ptr, cnt, W.params, nw, a, cap=4096) if nw else []
+        parts = R.gather([(q.start, q.end, q.height, q.prominence) for q in raw])
+        if R.rank != 0:
+            return None
+        flat = [am.Peak(*q) for part in parts for q in part]
+        return am.merge_peaks(W.params, flat)
+
+    for _ in range(max(1, warmup)):
+        res = step()
+    am._check(am.lib().am_device_synchronize(device))
+    R.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    local = time.perf_counter() - t0
+    dt = R.max_all(local)
+    ok = R.rank != 0 or [q.start for q in res] == plants
+    desc = R.gather({"rank": R.rank, "windows": nw, "first_window": w0, "samples": cnt, "seconds": round(local, 6)})
+    buf.free()
+    return dt / steps, ok, desc, n, len(plants)
+
+
 def device_identity(device: int) -> str:
     """Something that tells two physical GPUs apart across ranks: host name + the ordinal this rank
     uses (+ the visible-devices mask, which a launcher may set per rank)."""
@@ -506,6 +551,41 @@ def main():
 
     def sync():
         am._check(am.lib().am_device_synchronize(device))
+
+    if args.long_haystack > 0:
+        if args.config not in (1, 2):
+            raise SystemExit("bench.py: --long-haystack runs the config 2 workload")
+        am.set_option("profile_mask", 1 << KN.index(dom))
+        with am.Profile(device) as prof:
+            per_step, ok, parts, n_long, n_plants = long_haystack_leg(am, R, W, args.long_haystack, args.steps, args.warmup)
+            dom_ms, dom_launches = prof.query(dom)
+        if R.rank == 0:
+            # rank 0's K2: its part's block pairs go through the row kernel in launches of at most `pairs_per_group`
+            # pairs (each launch reads the needle spectrum once): bytes of all launches of a step over their time
+            g = plan_geometry(s, parts[0]["samples"], am.get_option("log_n") or 0) if parts[0]["samples"] >= s else None
+            ppg = am.get_option("pairs_per_group")
+            launches_per_step = -(-g["npairs"] // ppg) if g else 1
+            dom_bytes = ((g["npairs"] * g["n_fft"] * 16 + launches_per_step * g["n_fft"] * 8) / launches_per_step) if g else 0
+            dom_avg_s = dom_ms * 1e-3 / max(dom_launches, 1)
+            achieved = dom_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+            emit(json.dumps({
+                "metric": METRIC, "value": n_long / per_step, "unit": "samples/s", "n_gpus": devices_used, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"1 x 10 s mono 44.1 kHz f32 needle vs ONE {args.long_haystack:g} h haystack split over the ranks by "
+                                       f"window ranges (am_long_plan / am_match_part_device), one merge on rank 0 (am_merge_peaks); "
+                                       f"{n_plants} planted hits, offsets verified: {ok}",
+                           "baseline_config": 2, "haystack_samples": n_long, "ranks": R.world, "devices_used": devices_used,
+                           "ranks_per_device": rpd, "parts": parts, "offsets_ok": ok,
+                           "sharding": f"{R.world} rank(s), contiguous window ranges of one haystack, no collective (host gather of the peaks)"},
+                "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": dom_bytes,
+                             "avg_launch_us": dom_avg_s * 1e6, "launches": dom_launches,
+                             "note": "rank 0's part; bytes_per_launch is the average over the launches of a step"}}))
+            if not ok:
+                raise SystemExit("bench.py: --long-haystack: the merged offsets differ from the planted ones")
+        R.close()
+        return
 
     hays = []
     if not strong:
@@ -765,6 +845,15 @@ def side_measurements(am, device, algo, needle, params, hays, s, h, steps):
     out["end_to_end_pool_host_buffers"] = {"value": len(batch) * h / te, "unit": "samples/s",
                                            "note": "am_pool_match_batch, 4 host haystacks, two-slot ring: copy overlapped with match"}
     pool.close()
+    # (5) the host feed in numbers (host/pushbench.cpp, the C ABI from a C++ program): pageable against pinned buffers,
+    # pushes of 8 M, 64 K and the decoder's 1152 samples, CPU time of the pushing thread per GB
+    exe = os.path.join(ROOT, "audio-matcher_amd", "bin", "pushbench")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+            out["host_feed"] = json.loads(r.stdout) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            out["host_feed"] = {"error": str(e)[:300]}
     return out
 
 

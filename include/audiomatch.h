@@ -195,7 +195,12 @@ int am_match_pcm16_batch_device(const am_needle* h, const int16_t* const* d_inte
  * decoding) and matching overlap; finish runs what is left, picks the peaks and returns exactly
  * what am_match / am_match_pcm16 return for the concatenated samples, bit for bit.  After finish
  * the stream is empty again and can take the next file.  One producer per stream; streams on one
- * device share its queue. */
+ * device share its queue.
+ * A push never waits for the device when the piece is small (below 1 MB: the decoder's 1152-frame pieces,
+ * mp3_reader.rs:28-37): it is a host memcpy into a two-slot pinned staging ring, and a full slot (4 MB) leaves as
+ * one asynchronous copy while the other fills.  A larger piece is copied straight from the caller's buffer -- at link
+ * speed when that buffer is pinned (am_host_alloc / am_host_register) -- and push returns when the copy has left it.
+ * `samples` may be reused as soon as push returns, either way. */
 typedef struct am_stream am_stream;
 int am_match_stream_begin(const am_needle* h, int sample_format, size_t expected_len, const am_match_params* p, am_stream** out);
 int am_match_stream_push(am_stream* st, const void* samples, size_t n);
@@ -220,6 +225,17 @@ int am_device_free(int device, void* p);
 int am_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes);
 int am_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes);
 int am_device_synchronize(int device);
+
+/* Pinned host memory for the buffers handed to am_match, am_match_stream_push and am_pool_match_* (the reference
+ * collects the decoder's output in ordinary Vecs, mp3_reader.rs:13-41, matcher/mod.rs:32; nothing to pin there).
+ * The copy engines read pinned memory directly: no bounce buffer inside the runtime and no page faults, so the
+ * copier threads of a pool feed their devices side by side ("feeding the GPUs").  Either
+ * allocate the decoder's output buffer here, or register an existing allocation for the time it is in use.
+ * Portable across devices. */
+int am_host_alloc(size_t bytes, void** out);
+int am_host_free(void* p);
+int am_host_register(void* p, size_t bytes);
+int am_host_unregister(void* p);
 
 /* ---- synthetic signals for tests / benches -------- */
 /* d_out[k] = uniform(seed, stream, first + k) * amp, 24-bit exact in [-amp, amp) */

@@ -239,3 +239,78 @@ def test_isa_has_no_store_data_hazard(tmp_path):
         f = tmp_path / f"ok{i}.s"
         f.write_text("kern:\n\t" + asm + "\n\ts_endpgm\n")
         assert chk.check(str(f)) == [], asm
+
+
+def test_long_plan_partitions_the_windows(amlib):
+    """am_long_plan (one long haystack over several devices; audio_matcher.rs:104-131 fans the windows
+    of ONE haystack out) needs no device: the parts own contiguous window ranges that cover every window with a valid
+    lag exactly once, a part's samples reach to the end of its last window (chunk + overlap: the S - 1 halo and more),
+    part sizes differ by one window at most; also with full-length windows only (option tail_window = 1)."""
+    import random
+    rnd = random.Random(7)
+    for trial in range(300):
+        chunk = rnd.randint(1, 50)
+        overlap = rnd.randint(0, 60)
+        s = rnd.randint(1, 70)
+        n = rnd.randint(0, 700)
+        n_parts = rnd.randint(1, 6)
+        p = amlib.AmMatchParams(sr=1, chunk=chunk, overlap=overlap, min_prominence=0.1, min_distance=0,
+                                overshadow_distance_s=1.0, scale=1)
+        for tail in (0, 1):
+            amlib.set_option("tail_window", tail)
+            try:
+                window = chunk + overlap
+                valid = [i for i in range(0, (n + chunk - 1) // chunk)
+                         if min(window, n - i * chunk) >= s and (not tail or n - i * chunk >= window)]
+                assert valid == list(range(len(valid)))           # a prefix: only the windows at the end shrink
+                plans = [amlib.long_plan(n, s, p, n_parts, k) for k in range(n_parts)]
+                seen = []
+                for w0, nw, a, cnt in plans:
+                    seen += list(range(w0, w0 + nw))
+                    if nw:
+                        assert a == w0 * chunk and a + cnt == min(n, (w0 + nw - 1) * chunk + window)
+                    else:
+                        assert cnt == 0
+                assert seen == valid, (n, s, chunk, overlap, n_parts, tail)
+                sizes = [pl[1] for pl in plans]
+                assert max(sizes) - min(sizes) <= 1
+            finally:
+                amlib.set_option("tail_window", 0)
+    p = amlib.AmMatchParams(sr=1, chunk=10, overlap=2, min_prominence=0.1, min_distance=0, overshadow_distance_s=1.0, scale=1)
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.long_plan(100, 5, p, 2, 2)
+    with pytest.raises(amlib.AudioMatchError):
+        amlib.long_plan(100, 0, p, 2, 0)
+
+
+def test_merge_peaks_on_the_host_equals_the_checker(amlib, oracle):
+    """am_merge_peaks = sort by start + filter_surrounding(!is_overshadowed) (audio_matcher.rs:132-160) is host code
+    (no device needed): on random peak lists it keeps exactly what the checker's rule keeps, under both neighbour
+    policies; the reference's truth table (K3) included."""
+    import random
+    rnd = random.Random(11)
+    sr = 7
+    for trial in range(200):
+        n = rnd.randint(0, 12)
+        peaks = [amlib.Peak(rnd.randint(0, 200), 0, rnd.random(), rnd.choice([0.1, 0.2, 0.2, 0.5, rnd.random()])) for _ in range(n)]
+        for q in peaks:
+            q.end = q.start + 1
+        dist = rnd.choice([0.5, 1.0, 3.0, 10.0])
+        p = amlib.AmMatchParams(sr=sr, chunk=10, overlap=2, min_prominence=0.1, min_distance=0, overshadow_distance_s=dist, scale=1)
+        srt = sorted(peaks, key=lambda q: q.start)          # (stable: equal starts keep their order)
+        tup = [(q.start, q.end, q.height, q.prominence) for q in srt]
+        for from_filtered in (0, 1):
+            keep, last = [], None
+            for i, e in enumerate(tup):
+                before = (last if from_filtered else (tup[i - 1] if i else None))
+                after = tup[i + 1] if i + 1 < len(tup) else None
+                if oracle.is_overshadowed(e, before, sr, dist) or oracle.is_overshadowed(e, after, sr, dist):
+                    continue
+                keep.append(e)
+                last = e
+            amlib.set_option("surrounding_from", from_filtered)
+            try:
+                got = amlib.merge_peaks(p, peaks)
+            finally:
+                amlib.set_option("surrounding_from", 0)
+            assert [(g.start, g.end) for g in got] == [(e[0], e[1]) for e in keep], (trial, from_filtered)

@@ -393,3 +393,64 @@ def test_accumulating_k3_takes_any_score_pointer(gpu, oracle):
     inv = 1.0 / float(np.dot(needle.astype(np.float64), needle.astype(np.float64)))
     ref = np.array([np.dot(within[j:j + s].astype(np.float64), needle.astype(np.float64)) * inv for j in idx])
     assert np.abs(res[1][idx] - ref).max() < TOL
+
+
+# ---------------------------------------------------------------------------
+# host feed: staging ring of the stream, pinned host buffers
+# ---------------------------------------------------------------------------
+def test_stream_decoder_sized_pushes_and_pinned_buffers(gpu, oracle):
+    """am_match_stream_push with the decoder's piece size (1152 frames, mp3_reader.rs:28-37): every piece is a host
+    memcpy into the two-slot pinned staging ring, full slots leave asynchronously, pieces of 1 MB and more bypass the
+    ring -- in any mixture the result is am_match's, bit for bit, the block pairs are still transformed while the
+    samples arrive, and the stream is reusable.  The same from pinned host memory (am_host_alloc, am_host_register),
+    also through the pool's copier threads."""
+    sr = 8000
+    s = 2 * sr
+    needle = oracle.synth_uniform(61, 0, 0, s)
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=2.0, distance_s=30.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    algo = gpu.HipConvolve(needle)
+    hay = oracle.synth_uniform(62, 1, 0, 1150 * sr)
+    for t in (17.0, 300.5, 519.9, 1000.0, 1147.5):
+        off = int(t * sr)
+        hay[off:off + s] += needle
+    want = key(algo.match(hay, p))
+    assert [q[0] for q in want] == [int(t * sr) for t in (17.0, 300.5, 519.9, 1000.0, 1147.5)]
+    gpu.set_option("profile_mask", -1)
+    st = gpu.MatchStream(algo, p, hay.size)
+    with gpu.Profile(0) as prof:
+        push_pieces(st, hay, 1152)                                   # 8000 decoder-sized pieces
+        early = prof.query("k1_cols_fwd")[1]
+        assert key(st.finish()) == want
+    assert early >= 1, "no block pair was transformed while the samples arrived"
+    # a mixture: small pieces that straddle slot boundaries, pieces just below and at the direct-copy threshold, large ones
+    sizes = [1152] * 2000 + [300000, 1, 4607] + [4607] * 400 + [262143, 262144, 1 << 20, 5] + [99999] * 30 + [3000000]
+    off = 0
+    for k in sizes:
+        st.push(hay[off:off + k])
+        off += k
+    push_pieces(st, hay[off:], 1152)
+    assert key(st.finish()) == want
+    assert st.finish() == []
+    # the length unknown in advance: the device buffer grows while the ring holds samples that have not left yet
+    st2 = gpu.MatchStream(algo, p, 0)
+    push_pieces(st2, hay, 50000)
+    assert key(st2.finish()) == want
+    st2.close()
+    # pinned host memory: allocated by the library, or registered for the duration
+    pin = gpu.PinnedArray(hay.shape, np.float32)
+    pin.array[:] = hay
+    push_pieces(st, pin.array, 8 << 20)
+    assert key(st.finish()) == want
+    assert key(algo.match(pin.array, p)) == want
+    with gpu.registered(hay) as h:
+        push_pieces(st, h, 8 << 20)
+        assert key(st.finish()) == want
+    st.close()
+    pool = gpu.Pool(needle, [0, 0])
+    res = pool.match_batch([pin.array, hay, pin.array], p)
+    assert [key(r) for r in res] == [want] * 3
+    assert_close_peaks(pool.match_long(pin.array, p), algo.match(hay, p))
+    pool.close()
+    pin.free()
+    assert gpu.lib().am_host_alloc(0, None) == gpu.AM_ERR_INVALID_ARG
+    assert gpu.lib().am_host_register(None, 16) == gpu.AM_ERR_INVALID_ARG

@@ -104,3 +104,62 @@ def test_bench_control_plane_two_ranks(tmp_path):
     r = subprocess.run([sys.executable, "-c", "import sys, types; sys.path.insert(0, %r); import bench; bench.Rank(types.SimpleNamespace(gpus=4))" % ROOT],
                        env=dict(env, RANK="0"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
+
+
+LONG_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, os.path.join(%(root)r, "audio-matcher_amd", "python"))
+    sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+    import numpy as np
+    import torch.distributed as dist
+    import pyoracle as po
+    import audiomatch_amd as am
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sr, s = 2000, 2000
+    chunk, overlap = 10 * sr, s
+    needle = po.synth_uniform(3, 0, 0, s)
+    n = 95 * sr + 321
+    hay = po.synth_uniform(3, 1, 0, n)
+    for t, g in ((4.0, 1.0), (19.5, 1.0), (21.0, 0.7), (49.5, 1.0), (50.2, 0.8), (93.0, 1.0)):
+        off = int(t * sr)
+        hay[off:off + s] += np.float32(g) * needle
+    p = am.AmMatchParams(sr=sr, chunk=chunk, overlap=overlap, min_prominence=0.4, min_distance=sr // 2,
+                         overshadow_distance_s=3.0, scale=1)
+    w0, nw, a, cnt = am.long_plan(n, s, p, world, rank)        # a pure function: no device needed
+    raw = []
+    for i in range(w0, w0 + nw):                               # this rank's windows, as audio_matcher.rs:114-131 treats each
+        win = hay[i * chunk:min(n, i * chunk + chunk + overlap)]
+        sc = po.correlate(win, needle, po.MODE_VALID, po.SCALE_LIB)
+        raw += [(q[0] + i * chunk, q[1] + i * chunk, q[2], q[3]) for q in po.find_peaks(sc, 0.4, sr // 2)]
+    parts = [None] * world
+    dist.all_gather_object(parts, raw)
+    if rank == 0:
+        flat = [am.Peak(*q) for part in parts for q in part]
+        merged = am.merge_peaks(p, flat)                       # host code of the library: one merge over the union
+        whole = po.calc_chunks(sr, hay, needle, chunk, overlap, 0.4, sr // 2, 3.0)
+        print(json.dumps({"merged": [q.start for q in merged], "whole": [q[0] for q in whole], "raw": len(flat),
+                          "windows": [am.long_plan(n, s, p, world, r)[1] for r in range(world)]}))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_ranks_split_one_long_haystack(tmp_path):
+    """ONE haystack over two ranks (second sentence; bench.py --long-haystack): am_long_plan gives each
+    rank a window range, every rank picks its windows' peaks (the checker stands in for the device here), the lists are
+    gathered on the host and the library's am_merge_peaks runs ONE sort + overshadow pass over the union -- the
+    checker's answer for the whole haystack, including the weaker hit that is overshadowed across the cut."""
+    script = tmp_path / "long_worker.py"
+    script.write_text(LONG_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    import json
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    sr = 2000
+    assert res["windows"] == [5, 5]
+    assert res["merged"] == res["whole"] == [int(t * sr) for t in (4.0, 19.5, 49.5, 93.0)]
+    assert res["raw"] > len(res["merged"])
