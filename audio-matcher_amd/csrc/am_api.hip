@@ -69,6 +69,8 @@ static std::atomic<long long> g_opt_profile_mask{-1};    // bit i = bracket kern
 static std::atomic<long long> g_opt_half{0};             // 1 = half-precision storage of the work matrix (config 5)
 static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
 static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
+static std::atomic<long long> g_opt_pick_priority{0};    // 1 = the pick's stream is created with the lowest priority (read at context creation)
+static std::atomic<long long> g_opt_k3_group{1};         // 1 = the K3s of a needle group run as one launch (0: one launch per needle, for A/B)
 static std::atomic<long long> g_opt_device_redo{1};      // 0 = failed certificates are redone by the host path only (experiments)
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
 // test hooks (defaults = production behaviour)
@@ -84,7 +86,7 @@ static std::atomic<long long> g_opt_tail_window{0};         // 0 = chunked() emi
 static std::atomic<long long> g_opt_surrounding_from{0};    // filter_surrounding's neighbours: 0 = of the sorted, unfiltered sequence; 1 = the neighbour before is the last element kept
 struct Opts {
     long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo, debug_no_realloc, debug_redo_arm_at;
-    long long peak_filter_order, distance_rule, tail_window, surrounding_from;
+    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group;
     PeakPolicy peak_policy() const { return PeakPolicy{(int)peak_filter_order, (int)(distance_rule & 1), (int)((distance_rule >> 1) & 1)}; }
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
@@ -185,6 +187,9 @@ struct Ctx {
     // device-side redo (batches): a second work matrix, so that the inverse rows of haystack k are still there
     // when its pick has found chunks whose certificate failed, and the per-pair "run again" flags of both sets
     DevBuf work_b, redo_pairs[2];
+    // several needles: the K3s of a needle group run as ONE launch, every needle of the group with score-side
+    // buffers of its own; two such sets alternate (the picks of group g beside the transforms of group g + 1)
+    DevBuf grp_scores[2 * kMaxNeedleGroup], grp_stats32[2 * kMaxNeedleGroup], grp_wflags[2 * kMaxNeedleGroup];
     HostBuf failcnt;   // host-visible: one byte per chunk of a call, set when the chunk failed its certificate
     hipEvent_t ev_k3[2] = {nullptr, nullptr}, ev_pick[2] = {nullptr, nullptr};
     HostBuf pinned;
@@ -228,7 +233,17 @@ static int get_ctx(int device, Ctx** out) {
     c->spill.flags = hipHostMallocMapped | hipHostMallocCoherent;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return hip_fail(se, "hipStreamCreate"); }
-    (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    // the pick's stream: small, latency-bound kernels that run beside the next haystack's transforms; at the lowest
+    // priority their workgroups fill what the transform kernels leave free instead of competing for dispatch slots
+    // (option "pick_stream_priority", read when the context is created: 0 = same priority as the transforms)
+    {
+        int least = 0, greatest = 0;
+        if (g_opt_pick_priority.load(std::memory_order_relaxed) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            (void)hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least);
+        else
+            (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        (void)hipGetLastError();
+    }
     for (int i = 0; i < 2; ++i) {
         (void)hipEventCreateWithFlags(&c->ev_k3[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_pick[i], hipEventDisableTiming);
@@ -409,6 +424,7 @@ static Opts snapshot_opts(const am_needle* h) {
     o.distance_rule = g_opt_distance_rule.load(std::memory_order_relaxed);
     o.tail_window = g_opt_tail_window.load(std::memory_order_relaxed);
     o.surrounding_from = g_opt_surrounding_from.load(std::memory_order_relaxed);
+    o.k3_group = g_opt_k3_group.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -1551,6 +1567,14 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     if ((rc = c->wide_ctl.ensure(max_segs * 24))) return rc;
     if ((rc = c->wide_list.ensure(max_segs * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
     if ((rc = c->wide_tiles.ensure(max_segs * kWideTileList * sizeof(int)))) return rc;
+    // one K3 launch per needle group: every needle of a group (two groups in flight) has its own score-side buffers
+    const size_t k3_group = (o.k3_group && group_opt > 1 && nn > 1 && !o.half && max_wflags > 0) ? std::min(group_opt, nn) : 0;
+    for (size_t i = 0; i < k3_group * (overlap ? 2 : 1); ++i) {
+        const size_t slot = i < k3_group ? i : kMaxNeedleGroup + (i - k3_group);
+        if ((rc = c->grp_scores[slot].ensure(max_scores * sizeof(float)))) return rc;
+        if ((rc = c->grp_stats32[slot].ensure((max_scores + 31) / 32 * sizeof(float2)))) return rc;
+        if ((rc = c->grp_wflags[slot].ensure(max_wflags))) return rc;
+    }
     PeakArena arena{};
     if ((rc = prepare_results(c, nsegs * nn, nsegs * nn * 8 + 4096, &arena))) return rc;
     if ((rc = upload_segments(c, segs))) return rc;
@@ -1583,19 +1607,63 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
             am_needle* h = needles[j];
             const size_t in_group = j % group;
             const float2* inv_rows = (const float2*)c->work2.p + in_group * matrix;   // this needle's inverse rows
+            const size_t gn = std::min(group, nn - (j - in_group));
             if (group > 1 && in_group == 0) {
                 K2Group grp{};
-                grp.n = (int)std::min(group, nn - j);
+                grp.n = (int)gn;
                 for (int q = 0; q < grp.n; ++q) { grp.hc[q] = hc[j + q]; grp.dst[q] = (float2*)c->work2.p + (size_t)q * matrix; }
                 ProfScope ps(c, KN_K2);
                 AM_HIP(launch_k2_group(c->stream, (int)g.npairs, (const float2*)c->work.p, grp, pl->dev));
             }
+            // The K3s of the group as one launch (needle index on blockIdx.y), the group's picks queued behind it.
+            const bool grouped_k3 = k3_group && group > 1 && gn > 1 && fused && !half && plan_k3_has_group(pl->dev);
+            if (grouped_k3 && in_group != 0) continue;   // (handled with the group's first needle)
             const int set = overlap ? (int)(seq & 1) : 0;
+            const float margin = (!o.dense && p->min_prominence > 0.f) ? 0.5f * p->min_prominence : -1.0f;
+            if (grouped_k3) {
+                K3Group kg{};
+                kg.n = (int)gn;
+                ScanRequest scans[kMaxNeedleGroup];
+                ScanCfg common{};
+                for (size_t q = 0; q < gn; ++q) {
+                    am_needle* hq = needles[j + q];
+                    const size_t slot = (size_t)set * kMaxNeedleGroup + q;
+                    ScanRequest& sc = scans[q];
+                    sc = ScanRequest{};
+                    sc.set = 0;          // (the picks of a call run one after the other: they share the pick's own scratch)
+                    sc.margin = margin; sc.hist_min = hq->hist_min(sm);
+                    sc.seg_c = (long long)p->chunk; sc.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
+                    sc.bad = (src_kind == 0 || o.half) ? &h_bad[k] : nullptr;
+                    sc.fused = true;
+                    ScanCfg cfg{};
+                    fill_scan_cfg(&cfg, c->grp_stats32[slot].p, c->grp_wflags[slot].p, g.nblocks, pl->dev, margin, sc.hist_min, sc.seg_c, sc.seg_d);
+                    sc.sparse = sparse_view(cfg, g.hop, pl->dev);
+                    if (q == 0) common = cfg;
+                    kg.work[q] = (const float2*)c->work2.p + q * matrix;
+                    kg.dst[q] = (float*)c->grp_scores[slot].p;
+                    kg.stats32[q] = cfg.stats32; kg.wbits[q] = cfg.wbits; kg.tile_theta[q] = cfg.tile_theta;
+                    kg.hist_min[q] = cfg.hist_min;
+                    kg.out_scale[q] = half_scale(hq, o, pl->dev).k3(scale_factor(hq, p->scale, 1));
+                }
+                // K3 overwrites this set's scores and summaries: the picks that last read them must be done
+                if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
+                { ProfScope ps(c, KN_K3); AM_HIP(launch_k3_group(c->stream, job, (int)g.npairs, kg, pl->dev, common)); }
+                if (overlap) {
+                    AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
+                    AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
+                }
+                for (size_t q = 0; q < gn; ++q)
+                    if ((rc = launch_pick(c, kg.dst[q], out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
+                                          &scans[q], hdr_of(k, j + q), arena, pol, overlap ? c->stream2 : c->stream))) return rc;
+                if (overlap) AM_HIP(hipEventRecord(c->ev_pick[set], c->stream2));
+                ++seq;
+                continue;
+            }
             float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
             job.dst = d_scores;
             ScanRequest scan{};
             scan.set = set;
-            scan.margin = (!o.dense && p->min_prominence > 0.f) ? 0.5f * p->min_prominence : -1.0f;
+            scan.margin = margin;
             scan.hist_min = h->hist_min(sm);
             scan.seg_c = (long long)p->chunk;
             scan.seg_d = (long long)(p->chunk + p->overlap) - (long long)s;
@@ -2460,6 +2528,7 @@ int am_shutdown(void) {
         if (c->badflag.p) { (void)hipHostFree(c->badflag.p); c->badflag.p = nullptr; c->badflag.cap = 0; }
         if (c->failcnt.p) { (void)hipHostFree(c->failcnt.p); c->failcnt.p = nullptr; c->failcnt.cap = 0; }
         c->ranges.release(); c->range_flags.release(); c->big.release();
+        for (int i = 0; i < 2 * kMaxNeedleGroup; ++i) { c->grp_scores[i].release(); c->grp_stats32[i].release(); c->grp_wflags[i].release(); }
         c->segs_resident.clear();
         for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
         c->plans.clear();
@@ -2952,6 +3021,8 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "k3_group")) { g_opt_k3_group = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "pick_stream_priority")) { g_opt_pick_priority = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "peak_filter_order")) { g_opt_peak_filter_order = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "distance_rule")) {
         if (value < 0 || value > 3) return fail(AM_ERR_INVALID_ARG, "distance_rule out of range (bit 0: inclusive, bit 1: between plateau starts)");
@@ -2981,6 +3052,8 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
+    if (!strcmp(key, "k3_group")) { *value = g_opt_k3_group; return AM_OK; }
+    if (!strcmp(key, "pick_stream_priority")) { *value = g_opt_pick_priority; return AM_OK; }
     if (!strcmp(key, "peak_filter_order")) { *value = g_opt_peak_filter_order; return AM_OK; }
     if (!strcmp(key, "distance_rule")) { *value = g_opt_distance_rule; return AM_OK; }
     if (!strcmp(key, "tail_window")) { *value = g_opt_tail_window; return AM_OK; }

@@ -1591,13 +1591,16 @@ __device__ __forceinline__ void k3_finish(const Job& job, const ScanCfg& scan, c
 // pipeline twiddle, inverse 256-point column FFT, then k3_finish.  Output index of row n1,
 // column c is n1 * out_stride + c.
 template <bool ACC = false>
+// `geo` (needle-group launch): where the chunk edges come from -- the kernel argument itself, whose edge table is
+// indexed with a run-time slot; `scan` is then a per-needle copy whose pointers differ (a copy that were indexed
+// like that would have to live in scratch memory).
 __device__ __forceinline__ void k3_tile(const Job& job, const PlanDev& pl, const ScanCfg& scan, float2* lds2,
                                         int n2_0, int out_stride, int t, long long blkA, long long blkB,
-                                        float out_scale, float2 (&x0)[16], float2 (&x1)[16]) {
+                                        float out_scale, float2 (&x0)[16], float2 (&x1)[16], const ScanCfg* geo = nullptr) {
     const int hi = t >> 4, cp = t & 15;
     const long long N = 1ll << pl.logN;
     const long long col = n2_0 + 2 * cp;
-    const K3Edges ed = k3_edges(job, scan, blkA, blkB);
+    const K3Edges ed = k3_edges(job, geo ? *geo : scan, blkA, blkB);
     const unsigned maskN = (unsigned)(N - 1);
     const float2 w256 = pl.tw1[hi], w256q = pl.tw1[4 * hi];   // (fourth powers: see twiddle_apply(x, w, w4))
     {
@@ -1683,7 +1686,7 @@ __device__ __forceinline__ void k3_tile_h16(const Job& job, const PlanDev& pl, c
 // One column tile of the 256-row K3; lin = the tile's number in the launch (blockIdx.x in the pipeline's launches).
 template <int HALF, bool ACC>   // 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and an f16 first pass
 __device__ __forceinline__ void k3_cols_inv_r16_tile(unsigned lin, float4* lds4, const Job& job, const float2* __restrict__ work,
-                                                     const PlanDev& pl, float out_scale, const ScanCfg& scan) {
+                                                     const PlanDev& pl, float out_scale, const ScanCfg& scan, const ScanCfg* geo = nullptr) {
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     // XCD-aware placement (speed only): the 16 adjacent column tiles that share
@@ -1727,7 +1730,7 @@ __device__ __forceinline__ void k3_cols_inv_r16_tile(unsigned lin, float4* lds4,
             x1[bp] = make_float2(v.z, v.w);
         }
     }
-    k3_tile<ACC>(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1);
+    k3_tile<ACC>(job, pl, scan, reinterpret_cast<float2*>(lds4), n2_0, kN2, t, blkA, blkB, out_scale, x0, x1, geo);
 }
 // The kernel: one tile per workgroup.  REDO = the device-side redo's instantiation (a name of its own in kernel
 // traces): a SMALL grid walks the launch's tiles and runs those of the flagged pairs (scan.only_pairs) -- most
@@ -1745,6 +1748,19 @@ k3_cols_inv_r16(Job job, const float2* __restrict__ work, PlanDev pl, float out_
     } else {
         k3_cols_inv_r16_tile<HALF, ACC>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
     }
+}
+
+// the same for the 256-row plan (see k3_cols_inv_c512_group)
+__global__ void __launch_bounds__(256, AM_K3_WGS)
+k3_cols_inv_r16_group(Job job, PlanDev pl, ScanCfg scan, K3Group grp) {
+    extern __shared__ float4 lds4[];
+    const unsigned z = blockIdx.y;
+    job.dst = grp.dst[z];
+    ScanCfg mine;
+    mine.stats32 = grp.stats32[z]; mine.wbits = grp.wbits[z]; mine.tile_theta = grp.tile_theta[z]; mine.hist_min = grp.hist_min[z];
+    mine.margin = scan.margin; mine.seg_c = scan.seg_c; mine.seg_d = scan.seg_d; mine.inv_c = scan.inv_c;
+    mine.only_pairs = nullptr; mine.redo_tiles = 0; mine.edges_n = 0;
+    k3_cols_inv_r16_tile<0, false>(blockIdx.x, lds4, job, grp.work[z], pl, grp.out_scale[z], mine, &scan);
 }
 
 // ===========================================================================
@@ -1922,7 +1938,7 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
 
 template <int HALF, bool ACC>   // as in k1_cols_fwd_c512
 __device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4, const Job& job, const float2* __restrict__ work,
-                                                      const PlanDev& pl, float out_scale, const ScanCfg& scan) {
+                                                      const PlanDev& pl, float out_scale, const ScanCfg& scan, const ScanCfg* geo = nullptr) {
     float2* lds2 = reinterpret_cast<float2*>(lds4);
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
@@ -2024,7 +2040,7 @@ __device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4
             x1[bt] = T{v.z, v.w};
         }
     }
-    const K3Edges ed = k3_edges(job, scan, blkA, blkB);
+    const K3Edges ed = k3_edges(job, geo ? *geo : scan, blkA, blkB);
     const float2 w512 = pl.tw1[hi], w512q = pl.tw1[4 * hi];   // (fourth powers: see twiddle_apply(x, w, w4))
     {
         // out_scale rides on the pipeline twiddle: everything behind it is linear, the scan sees scores
@@ -2129,6 +2145,21 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     } else {
         k3_cols_inv_c512_tile<HALF, ACC>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
     }
+}
+
+// The needles of a group in one launch (launch_k3_group): blockIdx.y picks the needle, everything else is the
+// single-needle tile.  One launch instead of eight per group: no launch boundary -- and no drain of the previous
+// launch's dirty lines -- between the needles' K3s.
+__global__ void __launch_bounds__(512, 2)
+k3_cols_inv_c512_group(Job job, PlanDev pl, ScanCfg scan, K3Group grp) {
+    extern __shared__ float4 lds4[];
+    const unsigned z = blockIdx.y;
+    job.dst = grp.dst[z];
+    ScanCfg mine;   // (the scalar fields k3_finish reads; the edge table stays in the kernel argument: `geo`)
+    mine.stats32 = grp.stats32[z]; mine.wbits = grp.wbits[z]; mine.tile_theta = grp.tile_theta[z]; mine.hist_min = grp.hist_min[z];
+    mine.margin = scan.margin; mine.seg_c = scan.seg_c; mine.seg_d = scan.seg_d; mine.inv_c = scan.inv_c;
+    mine.only_pairs = nullptr; mine.redo_tiles = 0; mine.edges_n = 0;
+    k3_cols_inv_c512_tile<0, false>(blockIdx.x, lds4, job, grp.work[z], pl, grp.out_scale[z], mine, &scan);
 }
 
 // ===========================================================================
@@ -2607,6 +2638,8 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k3_cols_inv_r16<1, false, 1>), kR16LdsK3)
     AM_SET_LDS((k3_cols_inv_r16<2, false, 1>), kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_c1024<true>, kC1024Lds)
+    AM_SET_LDS(k3_cols_inv_c512_group, kC512Lds)
+    AM_SET_LDS(k3_cols_inv_r16_group, kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
     AM_SET_LDS((k3_cols_inv_c512<0, true>), kC512Lds)
     AM_SET_LDS((k3_cols_inv_r16<0, true>), kR16LdsK3)
@@ -2728,6 +2761,19 @@ static void fill_edges(const Job& job, int npairs, ScanCfg& scan) {
         scan.edge_rel[s][2] = rel(ecB, outB); scan.edge_rel[s][3] = rel(edB, outB);
     }
     scan.edges_n = npairs;
+}
+
+bool plan_k3_has_group(const PlanDev& pl) { return plan_is_c512(pl) || plan_is_r16(pl); }
+
+hipError_t launch_k3_group(hipStream_t st, const Job& job, int npairs, const K3Group& grp, const PlanDev& pl, const ScanCfg& scan_in) {
+    if (!plan_k3_has_group(pl) || grp.n < 1 || grp.n > kMaxNeedleGroup || scan_in.stats32 == nullptr) return hipErrorInvalidValue;
+    ScanCfg scan = scan_in;
+    scan.only_pairs = nullptr;
+    fill_edges(job, npairs, scan);
+    const dim3 grid((unsigned)npairs * (kN2 >> kColsLog), (unsigned)grp.n);
+    if (plan_is_c512(pl)) hipLaunchKernelGGL(k3_cols_inv_c512_group, grid, dim3(512), kC512Lds, st, job, pl, scan, grp);
+    else hipLaunchKernelGGL(k3_cols_inv_r16_group, grid, dim3(256), kR16LdsK3, st, job, pl, scan, grp);
+    return hipGetLastError();
 }
 
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,

@@ -101,6 +101,22 @@ struct ScanCfg {
 // accumulate: the scores are added to what job.dst holds (every run written; f32 work matrix only)
 hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* work,
                      const PlanDev& pl, float out_scale, const ScanCfg& scan, int half = 0, bool accumulate = false);
+// K3 for the needles of a group in ONE launch (BASELINE configs[3]): needle z = blockIdx.y reads its own inverse rows
+// and writes its own scores, summary, ballots and thresholds; block layout and chunk geometry are the group's (`job`,
+// `scan`: their dst / stats32 / wbits / tile_theta / hist_min fields are replaced per needle).  f32 work matrices of the
+// 512- and 256-row plans.
+struct K3Group {
+    int n;
+    const float2* work[kMaxNeedleGroup];
+    float* dst[kMaxNeedleGroup];
+    float2* stats32[kMaxNeedleGroup];
+    unsigned long long* wbits[kMaxNeedleGroup];
+    float* tile_theta[kMaxNeedleGroup];
+    float hist_min[kMaxNeedleGroup];
+    float out_scale[kMaxNeedleGroup];
+};
+bool plan_k3_has_group(const PlanDev& pl);
+hipError_t launch_k3_group(hipStream_t st, const Job& job, int npairs, const K3Group& grp, const PlanDev& pl, const ScanCfg& scan);
 // needles of at most this many samples are correlated by direct summation (no transform)
 constexpr int kDirectMaxNeedle = 64;
 hipError_t launch_direct(hipStream_t st, const Job& job, const float* needle, int s, float out_scale);

@@ -15,7 +15,7 @@ for cfg in 2 3 4; do
   find "$out/stats$cfg" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats_config$cfg.csv" \;
   rm -rf "$out/stats$cfg"
 done
-for cfg in 2 4; do
+for cfg in 2 3 4; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 200 rocprofv3 --pmc $c --output-format csv -d "$out/pmc$cfg/$c" -o run -- python3 bench.py --config $cfg $lean --steps 1 --warmup 1 --ramp-steps 0 --haystacks-per-step 3 > "$out/pmc${cfg}_$c.log" 2>&1 || exit 1
   done
