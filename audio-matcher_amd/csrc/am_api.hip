@@ -168,6 +168,7 @@ struct HostBuf {
 struct Plan {
     PlanDev dev{};
     float2* tables = nullptr;  // one allocation holding the four tables
+    unsigned* mf = nullptr;    // constant tables of the matrix-core row kernel (N2 = 8192 only)
 };
 
 struct ProfRec { int name; hipEvent_t e0, e1; };
@@ -304,6 +305,52 @@ static void fill_twiddles(std::vector<float2>& v, size_t off, size_t count, doub
     }
 }
 
+// Constant tables of k2_rows_m16 (am_fft.hip): the DFT-16 and DFT-32 matrices as operands of
+// v_mfma_f32_16x16x32_f16 -- lane (i = lane & 15, g = lane >> 4) holds row i, k = 8g .. 8g+7 with k = 2 p' + {re, im}
+// of input point p = 4g + p' (+ 16 ks): [Re F | -Im F] rows give the outputs' real parts, [Im F | Re F] the imaginary
+// parts, F[m][p] = W^(m p) -- and every thread's twiddles as h2: T1[gl][e][r] = W_8192^((32 (4w + gl) + 2n + e)(4g + r)),
+// T2[ch][r] = W_512^((16 ch + n)(4g + r)) for thread t = 64 w + 16 g + n.  Values are computed in f64 and rounded once.
+static void build_mfma_tables(std::vector<unsigned>& tab) {
+    tab.assign((size_t)k2_mfma_table_dwords(), 0u);
+    auto pack = [](double re, double im) {
+        const _Float16 a = (_Float16)re, b = (_Float16)im;
+        unsigned short ua, ub;
+        memcpy(&ua, &a, 2); memcpy(&ub, &b, 2);
+        return (unsigned)ua | ((unsigned)ub << 16);
+    };
+    // operand element pair (k = 2p', 2p'+1) of row m for input point p: real-part rows (cos, sin), imaginary-part rows (-sin, cos)
+    // with F = cos - i sin:  re_out = sum cos x_re + sin x_im,  im_out = sum -sin x_re + cos x_im
+    auto operand = [&](size_t base, int m_off, int p_off, double denom) {
+        for (int ri = 0; ri < 2; ++ri)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int pp = 0; pp < 4; ++pp) {
+                    const int m = m_off + (lane & 15), pt = p_off + 4 * (lane >> 4) + pp;
+                    const double ang = 2.0 * M_PI * (double)((m * pt) % (int)denom) / denom;
+                    tab[base + (size_t)ri * 256 + (size_t)lane * 4 + pp] = ri == 0 ? pack(std::cos(ang), std::sin(ang)) : pack(-std::sin(ang), std::cos(ang));
+                }
+    };
+    operand(0, 0, 0, 16.0);                                                   // A16: re rows, im rows
+    for (int mb = 0; mb < 2; ++mb)
+        for (int ks = 0; ks < 2; ++ks) operand(512 + (size_t)(mb * 2 + ks) * 512, 16 * mb, 16 * ks, 32.0);   // A32[mb][ks][re, im]
+    const size_t t1 = 512 + 2048, t2 = t1 + 256 * 32;
+    for (int t = 0; t < 256; ++t) {
+        const int w = t >> 6, g = (t >> 4) & 3, n = t & 15;
+        for (int gl = 0; gl < 4; ++gl)
+            for (int e = 0; e < 2; ++e)
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = ((long long)(32 * (4 * w + gl) + 2 * n + e) * (4 * g + r)) % 8192;
+                    const double ang = -2.0 * M_PI * (double)m / 8192.0;
+                    tab[t1 + (size_t)t * 32 + gl * 8 + e * 4 + r] = pack(std::cos(ang), std::sin(ang));
+                }
+        for (int ch = 0; ch < 2; ++ch)
+            for (int r = 0; r < 4; ++r) {
+                const int m = ((16 * ch + n) * (4 * g + r)) % 512;
+                const double ang = -2.0 * M_PI * (double)m / 512.0;
+                tab[t2 + (size_t)t * 8 + ch * 4 + r] = pack(std::cos(ang), std::sin(ang));
+            }
+    }
+}
+
 static int get_plan(Ctx* c, int logN, const Plan** out) {
     auto it = c->plans.find(logN);
     if (it != c->plans.end()) { *out = &it->second; return AM_OK; }
@@ -356,6 +403,14 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
     p.dev.twhi4 = reinterpret_cast<const float4*>(p.tables + o_hi4);
     p.dev.k2j = nk2j ? reinterpret_cast<const float4*>(p.tables + o_k2j) : nullptr;
     p.dev.k2c = nk2c ? reinterpret_cast<const float4*>(p.tables + o_k2c) : nullptr;
+    p.dev.mf = nullptr;
+    if (logN2 == 13) {
+        std::vector<unsigned> tab;
+        build_mfma_tables(tab);
+        AM_HIP(hipMalloc((void**)&p.mf, tab.size() * sizeof(unsigned)));
+        AM_HIP(copy_on_stream(c, p.mf, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        p.dev.mf = p.mf;
+    }
     auto ins = c->plans.emplace(logN, p);
     *out = &ins.first->second;
     return AM_OK;
@@ -371,6 +426,7 @@ struct am_needle {
     float inv_autocorr = 0.f;
     std::map<int, float2*> spectra;  // logN -> conj(H)/N in pipeline layout
     std::map<int, unsigned*> spectra16;   // logN -> the same as scaled __half2 points (half_pipeline = 2)
+    std::map<int, unsigned*> spectra16m;  // logN -> the same conjugated, in [a'][b'][c'] order (option k2_mfma)
     // Lowest chunk minimum of each of the last few haystacks matched with this needle (index 0:
     // unscaled scores, 1: AM_SCALE_LIB).  Bounds the raw-score write threshold from above, so that a
     // score array that drifts slowly (chunk minimum in another block pair than a tile's scores)
@@ -506,8 +562,10 @@ static int needle_spectrum(am_needle* h, const Plan* pl, const float2** out) {
 // half_pipeline = 2: the spectrum as __half2 points times `hscale` (fixed per needle and plan)
 static int needle_spectrum16(am_needle* h, const Plan* pl, float hscale, const float2** out) {
     const int key = pl->dev.logN;
-    auto it = h->spectra16.find(key);
-    if (it != h->spectra16.end()) { *out = reinterpret_cast<const float2*>(it->second); return AM_OK; }
+    const bool mfma = k2_mfma_enabled() && pl->dev.mf != nullptr && plan_k2_is_r16(pl->dev);   // (the matrix-core row kernel's layout)
+    std::map<int, unsigned*>& cache = mfma ? h->spectra16m : h->spectra16;
+    auto it = cache.find(key);
+    if (it != cache.end()) { *out = reinterpret_cast<const float2*>(it->second); return AM_OK; }
     const float2* hc = nullptr;
     int rc = needle_spectrum(h, pl, &hc);
     if (rc) return rc;
@@ -516,10 +574,11 @@ static int needle_spectrum16(am_needle* h, const Plan* pl, float hscale, const f
     unsigned* h16 = nullptr;
     AM_HIP(hipMalloc((void**)&h16, N * sizeof(unsigned)));
     hipError_t e;
-    { ProfScope ps(c, KN_OTHER); e = launch_spectrum_to_half(c->stream, hc, (long long)N, hscale, h16); }
+    { ProfScope ps(c, KN_OTHER);
+      e = mfma ? launch_spectrum_to_half_mfma(c->stream, hc, (long long)N, hscale, h16) : launch_spectrum_to_half(c->stream, hc, (long long)N, hscale, h16); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipFree(h16); return hip_fail(e, "needle spectrum (f16)"); }
-    h->spectra16[key] = h16;
+    cache[key] = h16;
     *out = reinterpret_cast<const float2*>(h16);
     return AM_OK;
 }
@@ -1914,10 +1973,12 @@ void am_needle_destroy(am_needle* h) {
         for (am_needle* sub : h->segments) {
             for (auto& kv : sub->spectra) (void)hipFree(kv.second);
             for (auto& kv : sub->spectra16) (void)hipFree(kv.second);
+            for (auto& kv : sub->spectra16m) (void)hipFree(kv.second);
             delete sub;
         }
         for (auto& kv : h->spectra) (void)hipFree(kv.second);
         for (auto& kv : h->spectra16) (void)hipFree(kv.second);
+        for (auto& kv : h->spectra16m) (void)hipFree(kv.second);
         if (h->d_needle && h->owns_data) (void)hipFree(h->d_needle);
     }
     delete h;
@@ -2530,7 +2591,7 @@ int am_shutdown(void) {
         c->ranges.release(); c->range_flags.release(); c->big.release();
         for (int i = 0; i < 2 * kMaxNeedleGroup; ++i) { c->grp_scores[i].release(); c->grp_stats32[i].release(); c->grp_wflags[i].release(); }
         c->segs_resident.clear();
-        for (auto& pk : c->plans) if (pk.second.tables) (void)hipFree(pk.second.tables);
+        for (auto& pk : c->plans) { if (pk.second.tables) (void)hipFree(pk.second.tables); if (pk.second.mf) (void)hipFree(pk.second.mf); }
         c->plans.clear();
         for (auto& r : c->pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         c->pending.clear();
@@ -3022,6 +3083,7 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "k3_group")) { g_opt_k3_group = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "k2_mfma")) { set_k2_mfma(value != 0); return AM_OK; }
     if (!strcmp(key, "pick_stream_priority")) { g_opt_pick_priority = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "peak_filter_order")) { g_opt_peak_filter_order = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "distance_rule")) {
@@ -3053,6 +3115,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
     if (!strcmp(key, "k3_group")) { *value = g_opt_k3_group; return AM_OK; }
+    if (!strcmp(key, "k2_mfma")) { *value = k2_mfma_enabled() ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "pick_stream_priority")) { *value = g_opt_pick_priority; return AM_OK; }
     if (!strcmp(key, "peak_filter_order")) { *value = g_opt_peak_filter_order; return AM_OK; }
     if (!strcmp(key, "distance_rule")) { *value = g_opt_distance_rule; return AM_OK; }

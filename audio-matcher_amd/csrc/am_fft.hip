@@ -41,6 +41,9 @@
 #include "am_kernels.h"
 
 #include <float.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <hip/hip_fp16.h>
 
@@ -1229,6 +1232,287 @@ __global__ void __launch_bounds__(256) spectrum_to_half_kernel(const float2* __r
 }
 hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out) {
     hipLaunchKernelGGL(spectrum_to_half_kernel, dim3(2048), dim3(256), 0, st, hc, n, scale, out);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// K2 with the 16- and 32-point butterflies on the matrix cores (option "k2_mfma", half_pipeline = 2): an A/B
+// experiment against k2_rows_h16, whose 2000 packed-f16 VALU instructions per wave are what bounds that kernel
+// (SQ counters, profiles/r04: VALU busy 0.83 at three waves per SIMD for half the f32 kernel's bytes).
+//
+// A 16-point DFT of 16 independent columns is one complex 16 x 16 matrix product, i.e. two real ones of shape
+// 16 x 32 x 16: v_mfma_f32_16x16x32_f16 with the DFT matrix as the A operand ([Re F | -Im F] for the real parts of
+// the outputs, [Im F | Re F] for the imaginary parts, k = 2 p + {re, im} of input point p) and the data as the B
+// operand: lane (n = lane & 15, g = lane >> 4) holds input points p = 4g .. 4g+3 of column n as four h2 registers
+// (exactly the operand's eight f16 k-values) and receives output points m = 4g .. 4g+3 of column n in f32.  The
+// 32-point pass is the same with two k-steps and two blocks of output rows (eight instructions per 16 columns).
+// The products are accumulated in f32 -- the packed butterflies round to f16 after every radix-2 stage.
+//
+// The row transform is the one of the other K2 kernels (n = a 512 + b 32 + c, k = a' + 16 b' + 256 c'; pass 1 over
+// a with the twiddle W_8192^(j a'), j = 32 b + c; pass 2 over b with W_512^(c b'); pass 3 over c), the inverse is
+// run as conj o forward o conj: the same DFT matrices and the same (forward) twiddles, applied to the inputs of
+// inverse passes 2 and 1; the conjugations at the two ends ride on the spectrum multiply (the spectrum is stored
+// conjugated, reordered to [a'][b'][c']: spectrum_to_half_mfma) and on the final conversion to f16.  Every twiddle a
+// lane needs is a per-lane constant: 32 + 8 h2 registers, fetched once per workgroup -- the workgroups are
+// persistent (a grid of four per CU walks the rows), so neither twiddle arithmetic nor seeds exist per row.
+//
+// Exchanges between the passes (one 33 KB LDS buffer, four workgroups per CU):
+//   E1 (pass 1 -> 2): 16 planes b of 512 rows (a', c), plane stride 516 dwords; written 8 bytes at a time (both
+//       columns 2n, 2n+1 of a lane), read as single dwords (a lane's four inputs b = 4g .. 4g+3 lie in four planes).
+//   E2 (pass 2 -> 3) and E3 (inverse pass 3 -> 2): private to a wave, one 2 KB block per a': E2 = [c][b'] with
+//       16-byte writes (b' = 4g .. 4g+3), E3 = [b'][c] likewise; XOR-swizzled so that the 16-byte writes and the
+//       dword reads are conflict-free.
+//   E4 (inverse pass 2 -> 1): 16 planes a' of 512 rows j, plane stride 520; dword writes, 8-byte reads.
+// E1 and E4 cross wavefronts: five workgroup barriers per row (write -> read of E1 and E4, and before a buffer
+// that other waves still read is overwritten).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+constexpr int kM16Ps1 = 516, kM16Ps4 = 520;
+constexpr int kK2mLds = 16 * kM16Ps4 * 4;   // 33 280 bytes
+// offsets (in dwords) of the constant tables behind PlanDev::mf (built by the host, am_api.hip build_mfma_tables)
+constexpr int kMfA16 = 0, kMfA32 = 2 * 64 * 4, kMfT1 = kMfA32 + 8 * 64 * 4, kMfT2 = kMfT1 + 256 * 32, kMfTotal = kMfT2 + 256 * 8;
+
+__device__ __forceinline__ half8 as_half8(const h2 (&v)[4]) {
+    u32x4v u;
+    u.x = h2_bits(v[0]); u.y = h2_bits(v[1]); u.z = h2_bits(v[2]); u.w = h2_bits(v[3]);
+    return __builtin_bit_cast(half8, u);
+}
+__device__ __forceinline__ half8 load_half8(const unsigned* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    u32x4v u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+    return __builtin_bit_cast(half8, u);
+}
+// 16-point DFT of the lane's column: inputs p = 4g .. 4g+3 in b, outputs m = 4g .. 4g+3 in y
+__device__ __forceinline__ void dft16_mfma(const half8& are, const half8& aim, const h2 (&b)[4], float2 (&y)[4]) {
+    const half8 bv = as_half8(b);
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4v dre = __builtin_amdgcn_mfma_f32_16x16x32_f16(are, bv, zero, 0, 0, 0);
+    const f32x4v dim = __builtin_amdgcn_mfma_f32_16x16x32_f16(aim, bv, zero, 0, 0, 0);
+    y[0] = make_float2(dre.x, dim.x); y[1] = make_float2(dre.y, dim.y);
+    y[2] = make_float2(dre.z, dim.z); y[3] = make_float2(dre.w, dim.w);
+}
+// conj(a) * b
+__device__ __forceinline__ h2 cmul_conj_a(h2 a, h2 b) {
+    const h2 t = a * b.xx;
+    return __builtin_elementwise_fma(a.yx, b.yy, (h2){t.x, -t.y});
+}
+__device__ __forceinline__ int swap_bits02(int c) { return (c & ~5) | ((c & 1) << 2) | ((c >> 2) & 1); }
+
+#ifndef AM_K2M_WAVES
+#define AM_K2M_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, AM_K2M_WAVES)
+k2_rows_m16(unsigned* __restrict__ work, const unsigned* __restrict__ hcm, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
+            float pre) {
+    extern __shared__ float4 lds4[];
+    unsigned* lds = reinterpret_cast<unsigned*>(lds4);
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, n = l & 15, g = l >> 4;
+    // ---- per-lane constants: the DFT-16 operands and every twiddle this lane ever applies ----
+    const half8 a16re = load_half8(pl.mf + kMfA16 + l * 4), a16im = load_half8(pl.mf + kMfA16 + 256 + l * 4);
+    h2 tw1[4][2][4], tw2[2][4];
+    {
+        const uint4* p1 = reinterpret_cast<const uint4*>(pl.mf + kMfT1 + t * 32);
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint4 v = p1[gl * 2 + e];
+                tw1[gl][e][0] = bits_h2(v.x); tw1[gl][e][1] = bits_h2(v.y); tw1[gl][e][2] = bits_h2(v.z); tw1[gl][e][3] = bits_h2(v.w);
+            }
+        const uint4* p2 = reinterpret_cast<const uint4*>(pl.mf + kMfT2 + t * 8);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const uint4 v = p2[ch];
+            tw2[ch][0] = bits_h2(v.x); tw2[ch][1] = bits_h2(v.y); tw2[ch][2] = bits_h2(v.z); tw2[ch][3] = bits_h2(v.w);
+        }
+    }
+    const h2 prescale = (h2){(_Float16)pre, (_Float16)pre};
+    // LDS addresses (dwords)
+    const int e1w = (4 * w) * kM16Ps1 + (4 * g) * 32 + 2 * n;            // + gl * Ps1 + r * 32        (8-byte writes)
+    const int e1r = (4 * g) * kM16Ps1 + (4 * w) * 32 + n;                // + r * Ps1 + q * 32 + 16 ch  (dword reads)
+    const int blk = (4 * w) * 512;                                         // + q * 512: the wave's private blocks
+    const int e2w = blk + swap_bits02(n) * 16 + ((g ^ (n & 3)) * 4);       // + q * 512 + 256 ch          (16-byte writes)
+    const int e2r = blk + (g & 1) * 16 + (g >> 1) * 128 + (n & 3);         // + q * 512 + ks * 256 + (r >> 1) * 32 + (r & 1) * 64 + ((n >> 2) ^ r) * 4
+    const int e3w = blk + n * 32 + ((g ^ (n & 7)) * 4);                    // + q * 512, ^ 16 for the second block of rows (16-byte writes)
+    const int e3r = blk + g * 128 + (n & 3);                               // + q * 512 + r * 32 + (ch ^ (g & 1)) * 16 + ((n >> 2) ^ r) * 4
+    const int e4w = (4 * w) * kM16Ps4 + g * 128 + n;                       // + q * Ps4 + r * 32 + 16 ch  (dword writes)
+    const int e4r = (4 * g) * kM16Ps4 + w * 128 + 2 * n;                   // + r * Ps4 + gl * 32         (8-byte reads)
+    const unsigned voff = (unsigned)(((4 * g) * 512 + 128 * w + 2 * n) * 4);   // + (r * 512 + 32 gl) * 4: the row's elements a 512 + 32 G + 2n
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned nseq = (npairs << pl.logN1) >> 3, sstep = gridDim.x >> 3;
+    for (unsigned seq = blockIdx.x >> 3; seq < nseq; seq += sstep) {
+        const unsigned row = (seq / npairs) * 8u + xcd, slot = seq % npairs;
+        const size_t row_off = ((size_t)slot << pl.logN) + (size_t)row * kN2;
+        const __amdgpu_buffer_rsrc_t rrow = make_rsrc(work + row_off, kN2 * 4);
+        const __amdgpu_buffer_rsrc_t rdst = dst ? make_rsrc(dst + row_off, kN2 * 4) : rrow;
+        // ---- pass 1: columns j = 32 G + 2n + e (G = 4w + gl), DFT over a ----
+        uint2 raw[4][4];
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) raw[gl][r] = buf_load_u2(rrow, voff, (unsigned)((r * 512 + 32 * gl) * 4));
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl) {
+            h2 b0[4], b1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { b0[r] = bits_h2(raw[gl][r].x) * prescale; b1[r] = bits_h2(raw[gl][r].y) * prescale; }
+            float2 y0[4], y1[4];
+            dft16_mfma(a16re, a16im, b0, y0);
+            dft16_mfma(a16re, a16im, b1, y1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const h2 v0 = cmul(to_h2(y0[r]), tw1[gl][0][r]), v1 = cmul(to_h2(y1[r]), tw1[gl][1][r]);
+                *reinterpret_cast<uint2*>(lds + e1w + gl * kM16Ps1 + r * 32) = make_uint2(h2_bits(v0), h2_bits(v1));
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: columns (a' = 4w + q, c = 16 ch + n), DFT over b ----
+        h2 bb[4][2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bb[q][ch][r] = bits_h2(lds[e1r + r * kM16Ps1 + q * 32 + 16 * ch]);
+        __syncthreads();   // E1 has been read by everybody: the waves' private blocks may overwrite it
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                float2 y[4];
+                dft16_mfma(a16re, a16im, bb[q][ch], y);
+                uint4 o;
+                o.x = h2_bits(cmul(to_h2(y[0]), tw2[ch][0])); o.y = h2_bits(cmul(to_h2(y[1]), tw2[ch][1]));
+                o.z = h2_bits(cmul(to_h2(y[2]), tw2[ch][2])); o.w = h2_bits(cmul(to_h2(y[3]), tw2[ch][3]));
+                *reinterpret_cast<uint4*>(lds + e2w + q * 512 + 256 * ch) = o;
+            }
+        wave_sync_lds();
+        // ---- pass 3 (DFT-32 over c), the spectrum multiply and inverse pass 3, one a' at a time ----
+        {
+            // (fetched per row -- 8 KB shared by every wave of the chip, L1-resident -- instead of living in 32 registers
+            // across the whole loop: the pointer is laundered so that the loads stay here)
+            const unsigned* a32p = pl.mf + kMfA32 + l * 4;
+            asm volatile("" : "+v"(a32p));
+            half8 a32[2][2][2];   // [block of output rows][k-step][re, im]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a32[i >> 2][(i >> 1) & 1][i & 1] = load_half8(a32p + i * 256);
+            const unsigned* hrow = hcm + ((size_t)row * 256 + (size_t)(4 * w) * 16 + n) * 32 + 4 * g;   // + q * 512 + 16 mb
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 hv0 = *reinterpret_cast<const uint4*>(hrow + q * 512), hv1 = *reinterpret_cast<const uint4*>(hrow + q * 512 + 16);
+                h2 bk[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        bk[ks][r] = bits_h2(lds[e2r + q * 512 + ks * 256 + (r >> 1) * 32 + (r & 1) * 64 + (((n >> 2) ^ r) * 4)]);
+                f32x4v d[2][2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) { d[mb][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; d[mb][1] = d[mb][0]; }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 bv = as_half8(bk[ks]);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        d[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[mb][ks][0], bv, d[mb][0], 0, 0, 0);
+                        d[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[mb][ks][1], bv, d[mb][1], 0, 0, 0);
+                    }
+                }
+                // product with the (conjugated, scaled) needle spectrum at k = a' + 16 b' + 256 c', c' = 16 mb + 4g + r:
+                // conj(z) * conj(h) = conj(z h) -- the inverse below is conj o forward o conj
+                h2 qv[2][4];
+                {
+                    const unsigned hh[2][4] = {{hv0.x, hv0.y, hv0.z, hv0.w}, {hv1.x, hv1.y, hv1.z, hv1.w}};
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const float zr[4] = {d[mb][0].x, d[mb][0].y, d[mb][0].z, d[mb][0].w};
+                        const float zi[4] = {d[mb][1].x, d[mb][1].y, d[mb][1].z, d[mb][1].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qv[mb][r] = cmul_conj_a(to_h2(make_float2(zr[r], zi[r])), bits_h2(hh[mb][r]));
+                    }
+                }
+                // inverse pass 3: the same DFT-32 on the conjugated product; its inputs c' sit where the outputs were
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) { d[mb][0] = (f32x4v){0.f, 0.f, 0.f, 0.f}; d[mb][1] = d[mb][0]; }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 bv = as_half8(qv[ks]);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        d[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[mb][ks][0], bv, d[mb][0], 0, 0, 0);
+                        d[mb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a32[mb][ks][1], bv, d[mb][1], 0, 0, 0);
+                    }
+                }
+                wave_sync_lds();   // (block q of E2 has been read; E3 takes its place)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {   // c = 16 mb + 4g + r of column (a', b' = n)
+                    uint4 o;
+                    o.x = h2_bits(to_h2(make_float2(d[mb][0].x, d[mb][1].x))); o.y = h2_bits(to_h2(make_float2(d[mb][0].y, d[mb][1].y)));
+                    o.z = h2_bits(to_h2(make_float2(d[mb][0].z, d[mb][1].z))); o.w = h2_bits(to_h2(make_float2(d[mb][0].w, d[mb][1].w)));
+                    *reinterpret_cast<uint4*>(lds + ((e3w + q * 512) ^ (mb * 16))) = o;
+                }
+            }
+        }
+        wave_sync_lds();
+        // ---- inverse pass 2: columns (a', c = 16 ch + n), twiddle W_512^(c b') on the inputs b' = 4g + r, DFT over b' ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bb[q][ch][r] = bits_h2(lds[e3r + q * 512 + r * 32 + ((ch ^ (g & 1)) * 16) + (((n >> 2) ^ r) * 4)]);
+        __syncthreads();   // every wave has read its blocks: E4 (all planes, all waves) may overwrite them
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                h2 bt[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bt[r] = cmul(bb[q][ch][r], tw2[ch][r]);
+                float2 y[4];
+                dft16_mfma(a16re, a16im, bt, y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[e4w + q * kM16Ps4 + r * 32 + 16 * ch] = h2_bits(to_h2(y[r]));   // b = 4g + r
+            }
+        __syncthreads();
+        // ---- inverse pass 1: columns j = 32 G + 2n + e, twiddle W_8192^(j a') on the inputs a' = 4g + r, DFT over a' ----
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) raw[gl][r] = *reinterpret_cast<const uint2*>(lds + e4r + r * kM16Ps4 + gl * 32);
+        __syncthreads();   // E4 has been read: the next row's pass 1 may write E1
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl) {
+            h2 b0[4], b1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { b0[r] = cmul(bits_h2(raw[gl][r].x), tw1[gl][0][r]); b1[r] = cmul(bits_h2(raw[gl][r].y), tw1[gl][1][r]); }
+            float2 y0[4], y1[4];
+            dft16_mfma(a16re, a16im, b0, y0);
+            dft16_mfma(a16re, a16im, b1, y1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)   // the final conjugation rides on the conversion
+                buf_store_u2(rdst, voff, (unsigned)((r * 512 + 32 * gl) * 4),
+                             make_uint2(h2_bits(to_h2(make_float2(y0[r].x, -y0[r].y))), h2_bits(to_h2(make_float2(y1[r].x, -y1[r].y)))));
+        }
+    }
+}
+
+// the needle spectrum for k2_rows_m16: conjugated, scaled, as h2 points in [row][a'][b'][c'] order (hc: the f32
+// spectrum in the register order of k2_rows_r16: float2 index 2t + 512 i + e of a row holds frequency
+// (a' = t >> 4, b' = t & 15, c' = brev32(2i + e)))
+__global__ void __launch_bounds__(256) spectrum_to_half_mfma_kernel(const float2* __restrict__ hc, long long n, float scale, unsigned* __restrict__ out) {
+    for (long long o = (long long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long long)gridDim.x * 256) {
+        const long long row = o >> kR16LogN2;
+        const int within = (int)(o & (kN2 - 1)), tt = within >> 5, cp = within & 31;
+        const int rr = brev<32>(cp), i = rr >> 1, e = rr & 1;
+        const float2 v = hc[row * kN2 + 2 * tt + 512 * i + e];
+        out[o] = h2_bits(to_h2(make_float2(v.x * scale, -v.y * scale)));
+    }
+}
+hipError_t launch_spectrum_to_half_mfma(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out) {
+    hipLaunchKernelGGL(spectrum_to_half_mfma_kernel, dim3(2048), dim3(256), 0, st, hc, n, scale, out);
     return hipGetLastError();
 }
 
@@ -2653,6 +2937,7 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
     AM_SET_LDS(k2_rows_r16_group, kR16Lds)
     AM_SET_LDS(k2_rows_h16, kK2hLds)
+    AM_SET_LDS(k2_rows_m16, kK2mLds)
 #undef AM_SET_LDS
     return hipSuccess;
 }
@@ -2694,11 +2979,25 @@ hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, c
     return hipGetLastError();
 }
 
+// (the environment variable AM_K2_MFMA sets the initial value, so that whole test runs can be repeated with it)
+static int k2_mfma_initial() { const char* e = getenv("AM_K2_MFMA"); return e && atoi(e) ? 1 : 0; }
+static std::atomic<int> g_k2_mfma{k2_mfma_initial()};
+void set_k2_mfma(int on) { g_k2_mfma.store(on ? 1 : 0, std::memory_order_relaxed); }
+bool k2_mfma_enabled() { return g_k2_mfma.load(std::memory_order_relaxed) != 0; }
+int k2_mfma_table_dwords() { return kMfTotal; }
+
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst,
                      int half, float hscale, float pre) {
     const dim3 grid(1u << pl.logN1, npairs);
     if (plan_k2_is_r16(pl)) {
-        if (half == 2) {
+        if (half == 2 && k2_mfma_enabled() && pl.mf != nullptr) {
+            // persistent workgroups: four per CU walk the rows (the grid stays a multiple of the 8 XCDs)
+            const unsigned rows = (unsigned)npairs << pl.logN1;
+            const unsigned grid = std::min<unsigned>(rows, 256u * 4u) & ~7u;
+            hipLaunchKernelGGL(k2_rows_m16, dim3(grid ? grid : 8u), dim3(256), kK2mLds, st,
+                               reinterpret_cast<unsigned*>(work), reinterpret_cast<const unsigned*>(hc), reinterpret_cast<unsigned*>(dst),
+                               pl, (unsigned)npairs, pre);
+        } else if (half == 2) {
             hipLaunchKernelGGL(k2_rows_h16, dim3((unsigned)npairs << pl.logN1), dim3(256), kK2hLds, st,
                                reinterpret_cast<unsigned*>(work), reinterpret_cast<const unsigned*>(hc), reinterpret_cast<unsigned*>(dst),
                                pl, (unsigned)npairs, pre);

@@ -41,6 +41,9 @@ struct PlanDev {
     // fourth powers, t < 256; k2c[2c] = (W^(32c), W^(32c+16)), k2c[2c+1] = their fourth powers, c < 16 (W = W_8192).
     const float4* k2j;
     const float4* k2c;
+    // constant tables of the matrix-core row kernel (k2_rows_m16, N2 = 8192 only; nullptr otherwise): DFT-16 and DFT-32
+    // operands in the lane layout of v_mfma_f32_16x16x32_f16 and every lane's twiddles as h2 (am_fft.hip kMf*)
+    const unsigned* mf;
 };
 
 constexpr int kColsLog = 5;            // B = 32 columns per K1/K3 workgroup
@@ -61,6 +64,12 @@ hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc,
                      int half = 0, float hscale = 1.0f, float pre = 1.0f);
 // half = 2: hc points at the __half2 form of the spectrum (launch_spectrum_to_half), hscale already in it
 hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out);
+// option "k2_mfma" (an A/B experiment for half_pipeline = 2): the row kernel's butterflies on the matrix cores;
+// it takes the spectrum conjugated and in [a'][b'][c'] order (launch_spectrum_to_half_mfma)
+void set_k2_mfma(int on);
+bool k2_mfma_enabled();
+int k2_mfma_table_dwords();
+hipError_t launch_spectrum_to_half_mfma(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out);
 hipError_t launch_k2_spectrum(hipStream_t st, float2* work, float2* hc_out, const PlanDev& pl);
 // A group of needles sharing one forward row transform (r16 rows, f32 storage only):
 // needle j multiplies with hc[j] and writes its inverse rows to dst[j].
