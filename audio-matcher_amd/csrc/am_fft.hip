@@ -1299,6 +1299,10 @@ __device__ __forceinline__ h2 cmul_conj_a(h2 a, h2 b) {
 }
 __device__ __forceinline__ int swap_bits02(int c) { return (c & ~5) | ((c & 1) << 2) | ((c >> 2) & 1); }
 
+// Measured (profiles/r04/k2_mfma_ab.txt): 869 VALU instructions per wave and row against the packed-f16 kernel's 2007,
+// and still slower -- 0.241 ms per launch against 0.210: the six passes of a row are one dependent chain with five
+// workgroup barriers, the kernel needs 216 registers (two waves per SIMD), and forms with fewer registers (the pass-1
+// twiddles fetched twice per row: 128 / 168 registers) or with prefetches ran at 0.28 - 0.36 ms.  Kept as an opt-in.
 #ifndef AM_K2M_WAVES
 #define AM_K2M_WAVES 2
 #endif

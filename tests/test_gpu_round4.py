@@ -454,3 +454,40 @@ def test_stream_decoder_sized_pushes_and_pinned_buffers(gpu, oracle):
     pin.free()
     assert gpu.lib().am_host_alloc(0, None) == gpu.AM_ERR_INVALID_ARG
     assert gpu.lib().am_host_register(None, 16) == gpu.AM_ERR_INVALID_ARG
+
+
+def test_matrix_core_row_kernel_is_result_equivalent(gpu, oracle):
+    """Option k2_mfma (an A/B experiment, off by default): the half-precision row kernel with its 16- and 32-point
+    butterflies as v_mfma_f32_16x16x32_f16 products.  Same offsets as the checker, scores within the half pipeline's
+    1e-3, on both register plans (2^21: 5 s needle, 2^22: 8 s needle) and through a second work matrix (several needles)."""
+    sr = 44100
+    gpu.set_option("k2_mfma", 1)
+    try:
+        for secs, seed in ((5.0, 91), (8.0, 92)):
+            s = int(secs * sr)
+            needles = [oracle.synth_uniform(seed, 300 + k, 0, s) for k in range(2)]
+            hay = oracle.synth_uniform(seed, 1, 0, 130 * sr)
+            plants = [[int(12.25 * sr), int(91.0 * sr)], [int(47.5 * sr)]]
+            for n_, offs in zip(needles, plants):
+                for off in offs:
+                    hay[off:off + s] += n_
+            p = gpu.Config(chunk_size_s=60.0, overlap_length_s=secs, distance_s=20.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+            algos = [gpu.HipConvolve(n_) for n_ in needles]
+            for a in algos:
+                a.set_option("half_pipeline", 2)
+            buf = gpu.DeviceBuffer.from_numpy(0, hay)
+            exps = [oracle.calc_chunks(sr, hay, n_, p.chunk, p.overlap, 0.13, p.min_distance, 20.0) for n_ in needles]
+            assert [[e[0] for e in ex] for ex in exps] == plants
+            for _ in range(2):
+                for a, ex in zip(algos, exps):
+                    assert_same(a.match_device(buf.ptr, hay.size, p), ex, tol=1e-3)
+            for got, ex in zip(gpu.match_multi_device(algos, buf.ptr, hay.size, p), exps):
+                assert_same(got, ex, tol=1e-3)
+            # the whole score vector of one window against the checker
+            win = hay[:3 * 1024 * 1024]
+            sc = algos[0].correlate_with_sample(win, gpu.Mode.Valid, True)
+            ref = oracle.correlate(win, needles[0], oracle.MODE_VALID, oracle.SCALE_LIB)
+            assert np.abs(sc - ref).max() < 1e-3
+    finally:
+        gpu.set_option("k2_mfma", 0)
+    assert gpu.get_option("k2_mfma") == 0

@@ -8,7 +8,7 @@ import glob
 import json
 import sys
 
-KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16<false", "k2_rows_r16_planes"), "k2_rows_h16": "k2_rows_h16", "k3_cols_inv": "k3_cols_inv_",
+KEYS = {"k1_cols_fwd": "k1_cols_fwd_", "k2_rows": ("k2_rows_r16<false", "k2_rows_r16_planes"), "k2_rows_h16": "k2_rows_h16", "k2_rows_m16": "k2_rows_m16", "k3_cols_inv": "k3_cols_inv_",
         "k2_rows_group": "k2_rows_r16_group"}
 
 
