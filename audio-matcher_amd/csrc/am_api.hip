@@ -70,6 +70,7 @@ static std::atomic<long long> g_opt_half{0};             // 1 = half-precision s
 static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
 static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
 static std::atomic<long long> g_opt_pick_priority{0};    // 1 = the pick's stream is created with the lowest priority (read at context creation)
+static std::atomic<long long> g_opt_pick_group{1};       // 1 = ... and so do the group's picks (0: four small launches per needle, for A/B)
 static std::atomic<long long> g_opt_k3_group{1};         // 1 = the K3s of a needle group run as one launch (0: one launch per needle, for A/B)
 static std::atomic<long long> g_opt_device_redo{1};      // 0 = failed certificates are redone by the host path only (experiments)
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
@@ -86,7 +87,7 @@ static std::atomic<long long> g_opt_tail_window{0};         // 0 = chunked() emi
 static std::atomic<long long> g_opt_surrounding_from{0};    // filter_surrounding's neighbours: 0 = of the sorted, unfiltered sequence; 1 = the neighbour before is the last element kept
 struct Opts {
     long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo, debug_no_realloc, debug_redo_arm_at;
-    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group;
+    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group, pick_group;
     PeakPolicy peak_policy() const { return PeakPolicy{(int)peak_filter_order, (int)(distance_rule & 1), (int)((distance_rule >> 1) & 1)}; }
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
@@ -191,6 +192,7 @@ struct Ctx {
     // several needles: the K3s of a needle group run as ONE launch, every needle of the group with score-side
     // buffers of its own; two such sets alternate (the picks of group g beside the transforms of group g + 1)
     DevBuf grp_scores[2 * kMaxNeedleGroup], grp_stats32[2 * kMaxNeedleGroup], grp_wflags[2 * kMaxNeedleGroup];
+    DevBuf grp_stats[kMaxNeedleGroup];   // tile summaries of the group's picks (one set: picks run one group after the other)
     HostBuf failcnt;   // host-visible: one byte per chunk of a call, set when the chunk failed its certificate
     hipEvent_t ev_k3[2] = {nullptr, nullptr}, ev_pick[2] = {nullptr, nullptr};
     HostBuf pinned;
@@ -481,6 +483,7 @@ static Opts snapshot_opts(const am_needle* h) {
     o.tail_window = g_opt_tail_window.load(std::memory_order_relaxed);
     o.surrounding_from = g_opt_surrounding_from.load(std::memory_order_relaxed);
     o.k3_group = g_opt_k3_group.load(std::memory_order_relaxed);
+    o.pick_group = g_opt_pick_group.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -972,6 +975,47 @@ static int launch_pick(Ctx* c, const float* d_scores, long long n_scores, int se
         AM_HIP(launch_peaks(st, d_scores, n_scores, (const float2*)bstats.p,
                             (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
                             (am_peak*)bpeaks.p, (SegHeader*)c->hdr.p + hdr_off, sp, arena, wide, only_failed, pol));
+    }
+    return AM_OK;
+}
+
+// The picks of a needle group (several needles against one haystack) as ONE set of launches: the level-1 summaries, the
+// per-chunk pick and its two follow-up kernels each run once with the needle on a grid dimension, instead of four small
+// launches per needle.  Every needle's result headers go to hdr_off[z] (absolute); scratch is laid out needle after needle.
+static int launch_pick_group(Ctx* c, const K3Group& kg, long long n_scores, int seg_off, int nsegs, float min_prom, long long min_dist,
+                             const SparseScores& sp_common, int* bad, const int* hdr_off, const PeakArena& arena, const PeakPolicy& pol,
+                             hipStream_t st) {
+    if (nsegs == 0 || n_scores <= 0 || kg.n <= 0) return AM_OK;
+    int rc;
+    const size_t nz = (size_t)kg.n, total = nz * (size_t)nsegs;
+    const long long ntiles = (n_scores + kTile - 1) / kTile;
+    PickGroup pg{};
+    pg.n = kg.n;
+    for (int z = 0; z < kg.n; ++z) {
+        if ((rc = c->grp_stats[z].ensure((size_t)ntiles * sizeof(float2)))) return rc;
+        pg.g[z] = kg.dst[z]; pg.stats[z] = static_cast<float2*>(c->grp_stats[z].p);
+        pg.stats32[z] = kg.stats32[z]; pg.wbits[z] = kg.wbits[z]; pg.theta[z] = kg.tile_theta[z];
+        pg.hdr_off[z] = hdr_off[z];
+    }
+    { ProfScope ps(c, KN_STATS, st);
+      AM_HIP(launch_stats_reduce(st, pg.stats32[0], n_scores, pg.stats[0], bad, &pg)); }
+    if ((rc = c->wide_ctl.ensure(total * 24))) return rc;
+    if ((rc = c->wide_list.ensure(total * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    if ((rc = c->wide_tiles.ensure(total * kWideTileList * sizeof(int)))) return rc;
+    if ((rc = c->peaks.ensure(total * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    WideState wide{};
+    wide.best = static_cast<unsigned long long*>(c->wide_ctl.p);
+    wide.state = reinterpret_cast<int*>(wide.best + total);
+    wide.count = reinterpret_cast<unsigned*>(wide.state + total);
+    wide.seg_min = reinterpret_cast<float*>(wide.state + 2 * total);
+    wide.ntiles = wide.state + 3 * total;
+    wide.tiles = static_cast<int*>(c->wide_tiles.p);
+    wide.list = static_cast<am_peak*>(c->wide_list.p);
+    wide.cap = AM_MAX_PEAKS_PER_CHUNK;
+    {
+        ProfScope ps(c, KN_PEAKS, st);
+        AM_HIP(launch_peaks(st, pg.g[0], n_scores, pg.stats[0], (const Segment*)c->segs.p + seg_off, nsegs, min_prom, min_dist,
+                            (am_peak*)c->peaks.p, (SegHeader*)c->hdr.p, sp_common, arena, wide, false, pol, &pg));
     }
     return AM_OK;
 }
@@ -1634,6 +1678,15 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         if ((rc = c->grp_stats32[slot].ensure((max_scores + 31) / 32 * sizeof(float2)))) return rc;
         if ((rc = c->grp_wflags[slot].ensure(max_wflags))) return rc;
     }
+    if (k3_group && o.pick_group) {   // ... and the scratch of the group's picks, which run as one set of launches
+        const size_t total = k3_group * max_segs;
+        for (size_t z = 0; z < k3_group; ++z)
+            if ((rc = c->grp_stats[z].ensure((max_scores + kTile - 1) / kTile * sizeof(float2)))) return rc;
+        if ((rc = c->wide_ctl.ensure(total * 24))) return rc;
+        if ((rc = c->wide_list.ensure(total * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+        if ((rc = c->wide_tiles.ensure(total * kWideTileList * sizeof(int)))) return rc;
+        if ((rc = c->peaks.ensure(total * AM_MAX_PEAKS_PER_CHUNK * sizeof(am_peak)))) return rc;
+    }
     PeakArena arena{};
     if ((rc = prepare_results(c, nsegs * nn, nsegs * nn * 8 + 4096, &arena))) return rc;
     if ((rc = upload_segments(c, segs))) return rc;
@@ -1711,6 +1764,12 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
                     AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
                     AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
                 }
+                if (o.pick_group) {
+                    int hoff[kMaxNeedleGroup];
+                    for (size_t q = 0; q < gn; ++q) hoff[q] = hdr_of(k, j + q);
+                    if ((rc = launch_pick_group(c, kg, out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance, scans[0].sparse,
+                                                scans[0].bad, hoff, arena, pol, overlap ? c->stream2 : c->stream))) return rc;
+                } else
                 for (size_t q = 0; q < gn; ++q)
                     if ((rc = launch_pick(c, kg.dst[q], out_count, seg_off[k], ns, p->min_prominence, (long long)p->min_distance,
                                           &scans[q], hdr_of(k, j + q), arena, pol, overlap ? c->stream2 : c->stream))) return rc;
@@ -2590,6 +2649,7 @@ int am_shutdown(void) {
         if (c->failcnt.p) { (void)hipHostFree(c->failcnt.p); c->failcnt.p = nullptr; c->failcnt.cap = 0; }
         c->ranges.release(); c->range_flags.release(); c->big.release();
         for (int i = 0; i < 2 * kMaxNeedleGroup; ++i) { c->grp_scores[i].release(); c->grp_stats32[i].release(); c->grp_wflags[i].release(); }
+        for (int i = 0; i < kMaxNeedleGroup; ++i) c->grp_stats[i].release();
         c->segs_resident.clear();
         for (auto& pk : c->plans) { if (pk.second.tables) (void)hipFree(pk.second.tables); if (pk.second.mf) (void)hipFree(pk.second.mf); }
         c->plans.clear();
@@ -3083,6 +3143,7 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "k3_group")) { g_opt_k3_group = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "pick_group")) { g_opt_pick_group = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "k2_mfma")) { set_k2_mfma(value != 0); return AM_OK; }
     if (!strcmp(key, "pick_stream_priority")) { g_opt_pick_priority = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "peak_filter_order")) { g_opt_peak_filter_order = value ? 1 : 0; return AM_OK; }
@@ -3115,6 +3176,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
     if (!strcmp(key, "k3_group")) { *value = g_opt_k3_group; return AM_OK; }
+    if (!strcmp(key, "pick_group")) { *value = g_opt_pick_group; return AM_OK; }
     if (!strcmp(key, "k2_mfma")) { *value = k2_mfma_enabled() ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "pick_stream_priority")) { *value = g_opt_pick_priority; return AM_OK; }
     if (!strcmp(key, "peak_filter_order")) { *value = g_opt_peak_filter_order; return AM_OK; }

@@ -140,7 +140,20 @@ hipError_t fft_kernels_init();
 hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment* ranges, int nranges, int* flags);
 // bad (optional, host-visible word): set to 1 when a score is not finite
 hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2* stats, int* bad = nullptr);
-hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats, int* bad = nullptr);
+// The picks of a needle group as one set of launches (several needles against one haystack): needle z (blockIdx.y / .z)
+// works on its own score array, summaries, flags and thresholds; chunk list and geometry are shared, results are laid
+// out needle after needle (n = 0: an ordinary, single pick).
+struct PickGroup {
+    int n;
+    const float* g[kMaxNeedleGroup];
+    float2* stats[kMaxNeedleGroup];
+    const float2* stats32[kMaxNeedleGroup];
+    const unsigned long long* wbits[kMaxNeedleGroup];
+    const float* theta[kMaxNeedleGroup];
+    int hdr_off[kMaxNeedleGroup];   // result headers of needle z: hdr + hdr_off[z] (relative to the pointer the launch is given)
+};
+hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats, int* bad = nullptr,
+                               const PickGroup* grp = nullptr);
 // per-chunk result header: the count, an overflow flag and the first few peaks
 // inline, so that the common case needs a single small device-to-host copy
 constexpr int kInlinePeaks = 4;
@@ -208,7 +221,7 @@ hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
-                        const WideState& wide, bool only_failed, const PeakPolicy& pol);
+                        const WideState& wide, bool only_failed, const PeakPolicy& pol, const PickGroup* grp = nullptr);
 // writes sumsq_parts(n) partial sums (one per workgroup) to d_parts
 int sumsq_parts(long long n);
 hipError_t launch_sumsq(hipStream_t st, const float* x, long long n, double* d_parts);

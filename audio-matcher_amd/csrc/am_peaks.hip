@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) tile_stats(const float* __restrict__ g, l
 // (a run of 32 scores that were all NaN has no ordered (min,max) pair; an infinite one shows in it)
 __device__ __forceinline__ bool bad_run(float mn, float mx) { return !(mn <= mx) || not_finite(mn) || not_finite(mx); }
 __global__ void __launch_bounds__(256) stats_reduce(const float2* __restrict__ s32, long long n32,
-                                                    float2* __restrict__ stats, long long ntiles, int* bad) {
+                                                    float2* __restrict__ stats, long long ntiles, int* bad, PickGroup grp) {
+    if (grp.n > 0) { s32 = grp.stats32[blockIdx.y]; stats = grp.stats[blockIdx.y]; }   // (one launch for the needles of a group)
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long tile = gid >> 3;
     const int l = threadIdx.x & 7;
@@ -672,11 +673,27 @@ __device__ __forceinline__ bool tile_can_qualify(const float2* tiles, long long 
     return true;
 }
 
+// One launch for the needles of a group (several needles against one haystack: the same chunks, one score array,
+// summary and flag set per needle): needle z sees its own arrays through the pointers the kernels index with the
+// chunk number -- results, hand-over state and lists are laid out needle after needle.
+__device__ __forceinline__ void pick_group_view(const PickGroup& grp, unsigned z, unsigned nsegs, const float*& g, const float2*& stats,
+                                                SparseScores& sp, SegHeader*& hdr, am_peak*& out, WideState& wide) {
+    g = grp.g[z];
+    stats = grp.stats[z];
+    sp.stats32 = grp.stats32[z]; sp.wbits = grp.wbits[z]; sp.tile_theta = grp.theta[z];
+    hdr += grp.hdr_off[z];
+    const size_t zs = (size_t)z * nsegs;
+    if (out != nullptr) out += zs * AM_MAX_PEAKS_PER_CHUNK;
+    wide.state += zs; wide.count += zs; wide.seg_min += zs; wide.best += zs; wide.ntiles += zs;
+    if (wide.tiles != nullptr) wide.tiles += zs * kWideTileList;
+    if (wide.list != nullptr) wide.list += zs * wide.cap;
+}
+
 __global__ void __launch_bounds__(kPeakThreads)
-peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
+peaks_kernel(const float* g, long long g_len, const float2* stats,
              const Segment* __restrict__ segs, float min_prom, long long min_dist,
-             am_peak* __restrict__ out, SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide,
-             int only_failed, PeakPolicy pol) {
+             am_peak* out, SegHeader* hdr, SparseScores sp, PeakArena arena, WideState wide,
+             int only_failed, PeakPolicy pol, PickGroup grp) {
     __shared__ float red[kWaves];
     __shared__ float seg_min_s;
     __shared__ Cand queue[kQueueCap];
@@ -694,6 +711,7 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
     __shared__ long long pe_s;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (grp.n > 0) pick_group_view(grp, blockIdx.y, gridDim.x, g, stats, sp, hdr, out, wide);
     const Segment sg = segs[blockIdx.x];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     am_peak* my_out = out + (size_t)blockIdx.x * AM_MAX_PEAKS_PER_CHUNK;
@@ -991,14 +1009,19 @@ peaks_kernel(const float* __restrict__ g, long long g_len, const float2* __restr
 // (p == 1 mod parts) and every kWideParts-th full tile, and appends what passes the
 // prominence filter to the chunk's list.
 __global__ void __launch_bounds__(kPeakThreads)
-peaks_wide(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
-           const Segment* __restrict__ segs, float min_prom, long long min_dist, SparseScores sp, WideState wide, PeakPolicy pol) {
+peaks_wide(const float* g, long long g_len, const float2* stats,
+           const Segment* __restrict__ segs, float min_prom, long long min_dist, SparseScores sp, WideState wide, PeakPolicy pol,
+           PickGroup grp) {
     __shared__ Cand queue[kWideQueue];
     __shared__ int queue_n;
     __shared__ int overflow;
     __shared__ float win[kWin];
     __shared__ float2 wruns[kWinRuns];
     const int seg = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    if (grp.n > 0) {
+        SegHeader* no_hdr = nullptr; am_peak* no_out = nullptr;
+        pick_group_view(grp, blockIdx.z, gridDim.y, g, stats, sp, no_hdr, no_out, wide);
+    }
     if (!(wide.state[seg] & 1)) return;
     const Segment sg = segs[seg];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
@@ -1142,14 +1165,15 @@ peaks_big_finish(const am_peak* __restrict__ list, unsigned n, long long a, long
 
 // grid nsegs: sort + distance filter of a chunk that went through peaks_wide
 __global__ void __launch_bounds__(kPeakThreads)
-peaks_finish(const float* __restrict__ g, long long g_len, const float2* __restrict__ stats,
-             const Segment* __restrict__ segs, float min_prom, long long min_dist, am_peak* __restrict__ out,
-             SegHeader* __restrict__ hdr, SparseScores sp, PeakArena arena, WideState wide, PeakPolicy pol) {
+peaks_finish(const float* g, long long g_len, const float2* stats,
+             const Segment* __restrict__ segs, float min_prom, long long min_dist, am_peak* out,
+             SegHeader* hdr, SparseScores sp, PeakArena arena, WideState wide, PeakPolicy pol, PickGroup grp) {
     __shared__ am_peak res[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int order[AM_MAX_PEAKS_PER_CHUNK];
     __shared__ int kept_s, spill_off_s;
     __shared__ long long pe_s;
     const int seg = blockIdx.x, tid = threadIdx.x;
+    if (grp.n > 0) pick_group_view(grp, blockIdx.y, gridDim.x, g, stats, sp, hdr, out, wide);
     if (!(wide.state[seg] & 1)) return;
     am_peak* my_out = out + (size_t)seg * AM_MAX_PEAKS_PER_CHUNK;
     const Segment sg = segs[seg];
@@ -1273,28 +1297,33 @@ hipError_t launch_tile_stats(hipStream_t st, const float* g, long long n, float2
     return hipGetLastError();
 }
 
-hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats, int* bad) {
+hipError_t launch_stats_reduce(hipStream_t st, const float2* stats32, long long n, float2* stats, int* bad, const PickGroup* grp) {
     const long long n32 = (n + 31) / 32;
     const long long tiles = (n + kTile - 1) / kTile;
     if (tiles <= 0) return hipSuccess;
     const long long blocks = (tiles * 8 + 255) / 256;
-    hipLaunchKernelGGL(stats_reduce, dim3((unsigned)blocks), dim3(256), 0, st, stats32, n32, stats, tiles, bad);
+    const PickGroup none{};
+    hipLaunchKernelGGL(stats_reduce, dim3((unsigned)blocks, grp ? (unsigned)grp->n : 1u), dim3(256), 0, st, stats32, n32, stats, tiles, bad,
+                       grp ? *grp : none);
     return hipGetLastError();
 }
 
 hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const float2* stats,
                         const Segment* d_segs, int nsegs, float min_prom, long long min_dist,
                         am_peak* d_out, SegHeader* d_hdr, const SparseScores& sp, const PeakArena& arena,
-                        const WideState& wide, bool only_failed, const PeakPolicy& pol) {
+                        const WideState& wide, bool only_failed, const PeakPolicy& pol, const PickGroup* grp) {
     if (nsegs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(peaks_kernel, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide, only_failed ? 1 : 0, pol);
+    const PickGroup none{};
+    const PickGroup& pg = grp ? *grp : none;
+    const unsigned nz = grp ? (unsigned)grp->n : 1u;
+    hipLaunchKernelGGL(peaks_kernel, dim3(nsegs, nz), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
+                       min_prom, min_dist, d_out, d_hdr, sp, arena, wide, only_failed ? 1 : 0, pol, pg);
     if (wide.list != nullptr) {
         // both return at once for chunks that peaks_kernel finished itself (the usual case)
-        hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                           min_prom, min_dist, sp, wide, pol);
-        hipLaunchKernelGGL(peaks_finish, dim3(nsegs), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs, min_prom, min_dist,
-                           d_out, d_hdr, sp, arena, wide, pol);
+        hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs, nz), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
+                           min_prom, min_dist, sp, wide, pol, pg);
+        hipLaunchKernelGGL(peaks_finish, dim3(nsegs, nz), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs, min_prom, min_dist,
+                           d_out, d_hdr, sp, arena, wide, pol, pg);
     }
     return hipGetLastError();
 }
@@ -1307,7 +1336,7 @@ hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment
 
 hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len, const float2* stats, const Segment* d_seg,
                                  float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide, const PeakPolicy& pol) {
-    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, min_prom, min_dist, sp, wide, pol);
+    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, min_prom, min_dist, sp, wide, pol, PickGroup{});
     return hipGetLastError();
 }
 hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
