@@ -71,6 +71,27 @@ extern "C" {
         pool: *mut AmPool, interleaved: *const *const i16, frames: *const usize, n_hay: usize,
         p: *const AmMatchParams, out: *mut AmPeak, cap_per_hay: usize, n_out: *mut usize,
     ) -> c_int;
+    /// ONE long haystack over the pool's devices (the window fan-out of audio_matcher.rs:104-131 across GPUs,
+    /// one sort + overshadow pass over the union, :132-140); sample_format 0 = f32 mono, 1 = i16 stereo frames
+    pub fn am_pool_match_long(
+        pool: *mut AmPool, haystack: *const std::ffi::c_void, len: usize, sample_format: c_int,
+        p: *const AmMatchParams, out: *mut AmPeak, cap: usize, n_out: *mut usize,
+    ) -> c_int;
+    /// the pieces of that, for one process per GPU: the split as a pure function, one part (peaks unmerged), the merge
+    pub fn am_long_plan(
+        len: usize, needle_len: usize, p: *const AmMatchParams, n_parts: usize, part: usize,
+        first_window: *mut usize, n_windows: *mut usize, first_sample: *mut usize, n_samples: *mut usize,
+    ) -> c_int;
+    pub fn am_match_part_device(
+        h: *const AmNeedle, d_part: *const std::ffi::c_void, n_samples: usize, sample_format: c_int, p: *const AmMatchParams,
+        n_windows: usize, first_sample: u64, out: *mut AmPeak, cap: usize, n_out: *mut usize,
+    ) -> c_int;
+    pub fn am_merge_peaks(p: *const AmMatchParams, peaks: *const AmPeak, n: usize, out: *mut AmPeak, cap: usize, n_out: *mut usize) -> c_int;
+    /// pinned host memory for the decoder's output (read by the copy engines without a bounce buffer)
+    pub fn am_host_alloc(bytes: usize, out: *mut *mut std::ffi::c_void) -> c_int;
+    pub fn am_host_free(p: *mut std::ffi::c_void) -> c_int;
+    pub fn am_host_register(p: *mut std::ffi::c_void, bytes: usize) -> c_int;
+    pub fn am_host_unregister(p: *mut std::ffi::c_void) -> c_int;
     /// several snippets of one length: the haystack's forward transform is shared by a group of needles
     pub fn am_match_multi_batch_device(
         needles: *const *const AmNeedle, n_needles: usize, d_haystacks: *const *const std::ffi::c_void,
@@ -269,6 +290,25 @@ impl HipConvolvePool {
                 return Err(am_err(rc));
             }
             return Ok((0..haystacks.len()).map(|k| buf[k * cap..k * cap + n[k]].to_vec()).collect());
+        }
+    }
+
+    /// calc_chunks on ONE long recording, its windows split over the pool's devices
+    pub fn match_long(&self, haystack: &[f32], p: &AmMatchParams) -> Result<Vec<AmPeak>, Box<dyn std::error::Error>> {
+        let mut cap = 4096usize;
+        loop {
+            let mut buf = vec![AmPeak::default(); cap];
+            let mut n = 0usize;
+            let rc = unsafe { am_pool_match_long(self.p, haystack.as_ptr().cast(), haystack.len(), 0, p, buf.as_mut_ptr(), cap, &mut n) };
+            if rc == AM_ERR_CAPACITY {
+                cap = n;
+                continue;
+            }
+            if rc != AM_OK {
+                return Err(am_err(rc));
+            }
+            buf.truncate(n);
+            return Ok(buf);
         }
     }
 }

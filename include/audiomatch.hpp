@@ -201,6 +201,25 @@ public:
         return out;
     }
 
+    // calc_chunks on ONE long haystack, its windows split over the pool's devices (audio_matcher.rs:104-131 fans the
+    // windows of one haystack out; one sort + overshadow pass over the union, :132-140)
+    std::vector<Peak> calc_chunks_long(std::uint16_t sr, const float* haystack, std::size_t len, bool scale, const Config& config,
+                                       std::size_t cap = 4096) {
+        const am_match_params p = config.params(sr, scale);
+        std::vector<am_peak> buf(cap);
+        std::size_t n = 0;
+        int rc = am_pool_match_long(p_, haystack, len, AM_FMT_F32_MONO, &p, buf.data(), cap, &n);
+        if (rc == AM_ERR_CAPACITY) {
+            buf.assign(n, am_peak{});
+            rc = am_pool_match_long(p_, haystack, len, AM_FMT_F32_MONO, &p, buf.data(), buf.size(), &n);
+        }
+        check(rc);
+        std::vector<Peak> out;
+        for (std::size_t j = 0; j < n; ++j)
+            out.push_back(Peak{static_cast<std::size_t>(buf[j].start), static_cast<std::size_t>(buf[j].end), buf[j].height, buf[j].prominence});
+        return out;
+    }
+
 private:
     am_pool* p_ = nullptr;
 };

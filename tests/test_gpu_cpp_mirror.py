@@ -43,6 +43,10 @@ int main(int argc, char** argv) {
     std::printf("pool %zu", pool.size());
     for (const auto& one : all) { std::printf(" |"); for (const Peak& p : one) std::printf(" %zu", p.start); }
     std::printf("\n");
+    // ONE haystack split over the pool's slots by window ranges (audio_matcher.rs:104-140 fanned out over devices)
+    std::printf("long");
+    for (const Peak& p : pool.calc_chunks_long(8000, hay.data(), hay.size(), true, cfg)) std::printf(" %zu", p.start);
+    std::printf("\n");
     // several snippets over the devices of the node: the second "snippet" is the first one delayed by 100 samples
     std::vector<float> shifted(needle.size(), 0.0f);
     for (size_t i = 100; i < needle.size(); ++i) shifted[i] = needle[i - 100];
@@ -90,6 +94,7 @@ def test_cpp_mirror_program(gpu, oracle, tmp_path):
         assert abs(float(p[2]) - e[2]) < 1e-4 and abs(float(p[3]) - e[3]) < 1e-4
     pool = [l for l in out if l.startswith("pool")][0]
     assert pool == f"pool 2 | {4 * sr} {17 * sr} | {4 * sr} | {4 * sr} {17 * sr}"
+    assert [l for l in out if l.startswith("long")] == [f"long {4 * sr} {17 * sr}"]
     # needle 2 = needle 1 delayed by 100 samples (its first 100 samples zero): its hits lie 100 samples earlier
     multi = [l for l in out if l.startswith("multi")][0]
     assert multi == f"multi | {4 * sr} {17 * sr} | {4 * sr - 100} {17 * sr - 100} | {4 * sr} | {4 * sr - 100}"
