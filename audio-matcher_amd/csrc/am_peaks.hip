@@ -636,6 +636,7 @@ __device__ void finish_best(const ChunkView& cv, unsigned long long key, am_peak
 // the 256 CUs idle for tens of milliseconds.)
 constexpr int kWideTiles = 0;
 constexpr int kWideParts = 64;
+constexpr int kWideRows = 16;    // chunks the grid of peaks_wide covers at a time (it strides over the rest)
 // a piece of at most kTile scores has at most kTile / 2 flat-topped maxima: the queue cannot overflow
 constexpr int kWideQueue = kTile / 2;
 
@@ -1010,19 +1011,23 @@ peaks_kernel(const float* g, long long g_len, const float2* stats,
 // prominence filter to the chunk's list.
 __global__ void __launch_bounds__(kPeakThreads)
 peaks_wide(const float* g, long long g_len, const float2* stats,
-           const Segment* __restrict__ segs, float min_prom, long long min_dist, SparseScores sp, WideState wide, PeakPolicy pol,
+           const Segment* __restrict__ segs, int nsegs, float min_prom, long long min_dist, SparseScores sp, WideState wide, PeakPolicy pol,
            PickGroup grp) {
     __shared__ Cand queue[kWideQueue];
     __shared__ int queue_n;
     __shared__ int overflow;
     __shared__ float win[kWin];
     __shared__ float2 wruns[kWinRuns];
-    const int seg = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const int part = blockIdx.x, tid = threadIdx.x;
     if (grp.n > 0) {
         SegHeader* no_hdr = nullptr; am_peak* no_out = nullptr;
-        pick_group_view(grp, blockIdx.z, gridDim.y, g, stats, sp, no_hdr, no_out, wide);
+        pick_group_view(grp, blockIdx.z, (unsigned)nsegs, g, stats, sp, no_hdr, no_out, wide);
     }
-    if (!(wide.state[seg] & 1)) return;
+    // The grid covers kWideRows chunks at a time and strides over the rest: almost every chunk is finished by peaks_kernel
+    // itself and only has its state looked at here -- one workgroup per (part, chunk) would be thousands of workgroups that
+    // start and return (0.6 ms of dispatch per launch for the 8 x 60 chunks of a needle group).
+    for (int seg = blockIdx.y; seg < nsegs; seg += gridDim.y) {
+    if (!(wide.state[seg] & 1)) continue;
     const Segment sg = segs[seg];
     const long long a = sg.a, b = sg.b < g_len ? sg.b : g_len;
     const long long tf = (a + kTile - 1) / kTile;
@@ -1064,6 +1069,8 @@ peaks_wide(const float* g, long long g_len, const float2* stats,
         }
     }
     if (tid == 0 && overflow) atomicAdd(&wide.count[seg], 0x40000000u);   // (cannot happen, see kWideQueue) poisons the count
+    __syncthreads();   // (the next chunk of this workgroup resets the queue)
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1320,8 +1327,8 @@ hipError_t launch_peaks(hipStream_t st, const float* g, long long g_len, const f
                        min_prom, min_dist, d_out, d_hdr, sp, arena, wide, only_failed ? 1 : 0, pol, pg);
     if (wide.list != nullptr) {
         // both return at once for chunks that peaks_kernel finished itself (the usual case)
-        hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs, nz), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
-                           min_prom, min_dist, sp, wide, pol, pg);
+        hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, nsegs < kWideRows ? nsegs : kWideRows, nz), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs,
+                           nsegs, min_prom, min_dist, sp, wide, pol, pg);
         hipLaunchKernelGGL(peaks_finish, dim3(nsegs, nz), dim3(kPeakThreads), 0, st, g, g_len, stats, d_segs, min_prom, min_dist,
                            d_out, d_hdr, sp, arena, wide, pol, pg);
     }
@@ -1336,7 +1343,7 @@ hipError_t launch_nonfinite_ranges(hipStream_t st, const float* x, const Segment
 
 hipError_t launch_peaks_wide_one(hipStream_t st, const float* g, long long g_len, const float2* stats, const Segment* d_seg,
                                  float min_prom, long long min_dist, const SparseScores& sp, const WideState& wide, const PeakPolicy& pol) {
-    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, min_prom, min_dist, sp, wide, pol, PickGroup{});
+    hipLaunchKernelGGL(peaks_wide, dim3(kWideParts, 1), dim3(kPeakThreads), 0, st, g, g_len, stats, d_seg, 1, min_prom, min_dist, sp, wide, pol, PickGroup{});
     return hipGetLastError();
 }
 hipError_t launch_peaks_big_finish(hipStream_t st, const am_peak* list, unsigned n, long long a, long long min_dist,
