@@ -73,6 +73,7 @@ static std::atomic<long long> g_opt_pick_priority{0};    // 1 = the pick's strea
 static std::atomic<long long> g_opt_pick_group{1};       // 1 = ... and so do the group's picks (0: four small launches per needle, for A/B)
 static std::atomic<long long> g_opt_k3_group{1};         // 1 = the K3s of a needle group run as one launch (0: one launch per needle, for A/B)
 static std::atomic<long long> g_opt_device_redo{1};      // 0 = failed certificates are redone by the host path only (experiments)
+static std::atomic<long long> g_opt_tail_block{1};       // 1 = a haystack's last, odd block goes through the next smaller plan (TailPlan); 0 = as half of a full pair
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
 // test hooks (defaults = production behaviour)
 static std::atomic<long long> g_opt_debug_no_realloc{0};     // 1 = a scratch buffer that would be (re)allocated while a call is queueing fails the call
@@ -87,7 +88,7 @@ static std::atomic<long long> g_opt_tail_window{0};         // 0 = chunked() emi
 static std::atomic<long long> g_opt_surrounding_from{0};    // filter_surrounding's neighbours: 0 = of the sorted, unfiltered sequence; 1 = the neighbour before is the last element kept
 struct Opts {
     long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo, debug_no_realloc, debug_redo_arm_at;
-    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group, pick_group;
+    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group, pick_group, tail_block;
     PeakPolicy peak_policy() const { return PeakPolicy{(int)peak_filter_order, (int)(distance_rule & 1), (int)((distance_rule >> 1) & 1)}; }
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
@@ -180,6 +181,9 @@ struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;           // peak pick of haystack k beside the transforms of k+1 (batches)
+    hipStream_t stream_tail = nullptr;       // a haystack's odd last block on the smaller plan, beside its main pass (run_tail_block)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf work_tail, tail_scores, tail_stats;   // (a batch computes the tails of up to kMaxTailBatch haystacks per launch: two alternating halves)
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
     DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur, wide_ctl, wide_list, wide_tiles;
@@ -247,6 +251,10 @@ static int get_ctx(int device, Ctx** out) {
             (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
         (void)hipGetLastError();
     }
+    (void)hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    (void)hipGetLastError();
     for (int i = 0; i < 2; ++i) {
         (void)hipEventCreateWithFlags(&c->ev_k3[i], hipEventDisableTiming);
         (void)hipEventCreateWithFlags(&c->ev_pick[i], hipEventDisableTiming);
@@ -484,6 +492,7 @@ static Opts snapshot_opts(const am_needle* h) {
     o.surrounding_from = g_opt_surrounding_from.load(std::memory_order_relaxed);
     o.k3_group = g_opt_k3_group.load(std::memory_order_relaxed);
     o.pick_group = g_opt_pick_group.load(std::memory_order_relaxed);
+    o.tail_block = g_opt_tail_block.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -608,6 +617,7 @@ struct ScanRequest {
     // when the real length gives fewer blocks.
     long long side_nblocks;
     bool skip_launch;
+    bool tail_by_caller;     // in: the caller computes a TailPlan's scores itself (match_many, several haystacks per launch): main pass only
     bool no_scan;            // in: only the block restriction (range_a, range_b) applies; K3 writes plain scores
     bool work_by_set;        // in: the work matrix of set 1 is the context's second one (kept for a device-side redo)
     // out: what a second K3 launch over the same work matrix needs (valid when redo_ok)
@@ -630,6 +640,36 @@ static int plan_geometry(size_t s, long long out_count, const Opts& o, Geometry*
     g->npairs = (g->nblocks + 1) / 2;
     return AM_OK;
 }
+// The odd last block.  Two blocks share one complex transform, so a haystack with an odd number of blocks pays a
+// whole pair for its last, usually part-filled block (1 h at 44.1 kHz against a 10 s needle: 42.2 blocks of the
+// 2^22 plan = 22 pairs, 2.3 % of the points for nothing).  When the scores behind the last even block boundary T fit
+// into one pair of a smaller plan that has the fused scan, the main pass stops at T and those scores come from
+// that plan, computed on a stream of their own beside the main pass (run_tail_block): every run written, and the
+// main layout's ballots / thresholds of the block they belong to preset to "all written", so that the peak pick
+// sees one score array with one geometry.  Which blocks a haystack gets depends on its own length only: its bits
+// do not depend on the batch it travels in.
+struct TailPlan {
+    bool on;
+    long long T;      // first score of the tail (a multiple of the main plan's hop, hence of kTile)
+    Geometry g;       // the smaller plan's layout for scores [T, out_count): one pair
+};
+static bool tail_plan(size_t s, long long out_count, const Opts& o, const Geometry& g, TailPlan* t) {
+    t->on = false;
+    if (!o.tail_block || o.log_n != 0 || g.logN < 22 || !(g.nblocks & 1) || g.nblocks < 3 || (g.hop % kTile) != 0) return false;
+    const long long T = (g.nblocks - 1) * g.hop, rest = out_count - T;
+    for (int lt = 21; lt < g.logN; ++lt) {   // (2^21 is the smallest plan whose K3 carries the scan)
+        const long long N = 1ll << lt;
+        long long hop = N - (long long)s + 1;
+        if (hop < 8 * kTile) continue;
+        hop = (hop / kTile) * kTile;
+        if (2 * hop < rest) continue;
+        t->on = true; t->T = T;
+        t->g.logN = lt; t->g.N = N; t->g.hop = hop; t->g.nblocks = (rest + hop - 1) / hop; t->g.npairs = 1;
+        return true;
+    }
+    return false;
+}
+
 // Half-precision levels (option "half_pipeline"): 1 = the work matrix travels through HBM as f16,
 // butterflies in f32; 2 = K2's butterflies in packed f16 as well.  The scales keep every stored
 // or f16-computed value inside f16's range: level 1 normalises K2's product by the needle energy
@@ -700,6 +740,43 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
                                float* d_dst, long long out_count, float factor,
                                ScanRequest* scan_req, int src_kind, bool accumulate);
 
+// The scores [tail.T, out_count) of a haystack on the smaller plan (TailPlan), queued on the context's tail stream:
+// one block pair through K1 / K2 / K3 with every run written and the level-0 summary at its place in the main
+// pass's stats32; then block `main_nblocks - 1` of the MAIN layout is marked "every run written, threshold -inf".
+static int run_tail_block(am_needle* h, const Opts& o, const TailPlan& tail, const void* d_src, long long src_len,
+                          float* d_dst, long long out_count, float factor, const ScanCfg& main_scan, const PlanDev& main_pl,
+                          long long main_nblocks, int src_kind) {
+    Ctx* c = h->ctx;
+    hipStream_t st = c->stream_tail;
+    int rc;
+    const Plan* pl = nullptr;
+    if ((rc = get_plan(c, tail.g.logN, &pl))) return rc;
+    const float2* hc = nullptr;
+    if ((rc = needle_spectrum(h, pl, &hc))) return rc;
+    const HalfScale hs = half_scale(h, o, pl->dev);
+    if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hc))) return rc;
+    if ((rc = c->work_tail.ensure((size_t)tail.g.N * sizeof(float2)))) return rc;
+    Job job{};
+    job.src = static_cast<const char*>(d_src) + 4 * (size_t)tail.T;   // (one f32 sample and one i16 stereo frame are both 4 bytes)
+    job.src_len = src_len - tail.T; job.lead = 0; job.src_kind = src_kind;
+    job.dst = d_dst + tail.T; job.out_count = out_count - tail.T; job.hop = (int)tail.g.hop; job.nblocks = (int)tail.g.nblocks;
+    job.first_pair = 0;
+    ScanCfg scan{};
+    scan.stats32 = main_scan.stats32 ? main_scan.stats32 + tail.T / 32 : nullptr;
+    scan.margin = -1.0f; scan.hist_min = FLT_MAX;
+    // (profiled as "other": the three classes' figures stay those of the main pass's launches)
+    { ProfScope ps(c, KN_OTHER, st); AM_HIP(launch_k1(st, job, 1, (float2*)c->work_tail.p, pl->dev, hs.level)); }
+    { ProfScope ps(c, KN_OTHER, st); AM_HIP(launch_k2(st, 1, (float2*)c->work_tail.p, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre, true)); }
+    { ProfScope ps(c, KN_OTHER, st); AM_HIP(launch_k3(st, job, 1, (const float2*)c->work_tail.p, pl->dev, hs.k3(factor), scan, hs.level, false)); }
+    if (main_scan.stats32 && main_scan.margin >= 0.0f && main_scan.wbits && main_scan.tile_theta) {
+        const size_t tiles = (size_t)1 << (main_pl.logN2 - kColsLog), words = tiles << (main_pl.logN1 - 6);
+        const size_t blk = (size_t)(main_nblocks - 1);
+        AM_HIP(hipMemsetAsync(main_scan.wbits + blk * words, 0xFF, words * sizeof(unsigned long long), st));
+        AM_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(main_scan.tile_theta + blk * tiles), (int)0xFF7FFFFFu, tiles, st));   // -FLT_MAX
+    }
+    return AM_OK;
+}
+
 // The overlap-save engine for any needle length: one pass, or one pass per needle segment with the
 // source shifted by the segment's offset and K3 adding up the partial sums (plain scores, every one
 // written; the peak pick summarises them with tile_stats instead of the fused scan).
@@ -759,7 +836,13 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
     if ((rc = get_plan(c, g.logN, &pl))) return rc;
     const float2* hc = nullptr;
     if ((rc = needle_spectrum(h, pl, &hc))) return rc;
-    const long long N = g.N, hop = g.hop, nblocks = g.nblocks, npairs = g.npairs;
+    const long long N = g.N, hop = g.hop, nblocks = g.nblocks;
+    // (streaming ingest launches its pairs itself, under the layout of the announced length: no tail there)
+    TailPlan tail{};
+    if (scan_req && !scan_req->no_scan && !accumulate && lead == 0 && !scan_req->ext_stats32 && !scan_req->ext_side &&
+        !scan_req->skip_launch && scan_req->side_nblocks == 0 && plan_has_scan(pl->dev) && c->stream_tail && c->ev_fork && c->ev_join)
+        tail_plan(h->n, out_count, o, g, &tail);
+    const long long npairs = tail.on ? g.npairs - 1 : g.npairs;   // block pairs of the main pass
     long long ppg = std::max<long long>(1, o.pairs_per_group);
     if (ppg > npairs) ppg = npairs;
     DevBuf& wk = (scan_req && scan_req->work_by_set && scan_req->set) ? c->work_b : c->work;
@@ -787,12 +870,23 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
     if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hc))) return rc;
     Job job{};
     job.src = d_src; job.src_len = src_len; job.lead = lead; job.src_kind = src_kind;
-    job.dst = d_dst; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks;
+    job.dst = d_dst; job.out_count = tail.on ? tail.T : out_count; job.hop = (int)hop; job.nblocks = (int)(tail.on ? nblocks - 1 : nblocks);
     if (scan_req && scan_req->skip_launch) return AM_OK;
     long long pair_lo = 0, pair_hi = npairs;
+    bool with_tail = tail.on;
     if (scan_req && scan_req->range_b > scan_req->range_a) {
         pair_lo = (scan_req->range_a / hop) / 2;
         pair_hi = std::min(npairs, ((scan_req->range_b - 1) / hop) / 2 + 1);
+        with_tail = tail.on && scan_req->range_b > tail.T;
+    }
+    if (scan_req && scan_req->tail_by_caller) with_tail = false;
+    if (with_tail) {
+        // beside the main pass: everything this stream has been told to wait for (the pick that last read the set)
+        // holds for the tail's stream too, and the main stream takes the tail back in before anything reads the scores
+        AM_HIP(hipEventRecord(c->ev_fork, c->stream));
+        AM_HIP(hipStreamWaitEvent(c->stream_tail, c->ev_fork, 0));
+        if ((rc = run_tail_block(h, o, tail, d_src, src_len, d_dst, out_count, factor, scan, pl->dev, nblocks, src_kind))) return rc;
+        AM_HIP(hipEventRecord(c->ev_join, c->stream_tail));
     }
     bool waited = false;
     for (long long first = pair_lo; first < pair_hi; first += ppg) {
@@ -804,6 +898,7 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
         waited = true;
         { ProfScope ps(c, KN_K3); AM_HIP(launch_k3(c->stream, job, np, (const float2*)wk.p, pl->dev, k3scale, scan, hs.level, accumulate)); }
     }
+    if (with_tail) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (scan_req && scan_req->fused && !accumulate && pair_lo == 0 && pair_hi == npairs && npairs <= ppg) {
         // the whole haystack's inverse rows sit in one work matrix: K3 can run again over chosen pairs
         scan_req->redo_ok = true;
@@ -818,10 +913,11 @@ static int run_correlation_one(am_needle* h, const Opts& o, const void* d_src, l
 // once, for its largest haystack, before anything is queued (see QueueingScope).  Also builds the plan and
 // the needle spectrum the haystack will use (building one runs kernels and waits for them).
 struct Footprint {
-    size_t work = 0, stats32 = 0, side = 0;
+    size_t work = 0, stats32 = 0, side = 0, work_tail = 0;
     long long npairs = 0;
     void take(const Footprint& f) {
         work = std::max(work, f.work); stats32 = std::max(stats32, f.stats32); side = std::max(side, f.side);
+        work_tail = std::max(work_tail, f.work_tail);
         npairs = std::max(npairs, f.npairs);
     }
 };
@@ -854,6 +950,15 @@ static int correlation_footprint(am_needle* h, const Opts& o, long long out_coun
     if (plan_has_scan(pl->dev) && (g.hop % kTile) == 0) {
         f->stats32 = std::max(f->stats32, (size_t)((out_count + 31) / 32) * sizeof(float2));
         f->side = std::max(f->side, sparse_bytes(g.nblocks, pl->dev));
+        TailPlan tail{};
+        if (tail_plan(h->n, out_count, o, g, &tail)) {   // (plan and spectrum of the odd last block's transform, see run_tail_block)
+            const Plan* plt = nullptr;
+            if ((rc = get_plan(h->ctx, tail.g.logN, &plt))) return rc;
+            if ((rc = needle_spectrum(h, plt, &hc))) return rc;
+            const HalfScale hst = half_scale(h, o, plt->dev);
+            if (hst.level == 2 && (rc = needle_spectrum16(h, plt, hst.hscale, &hc))) return rc;
+            f->work_tail = std::max(f->work_tail, (size_t)tail.g.N * sizeof(float2));
+        }
     }
     return AM_OK;
 }
@@ -1139,6 +1244,57 @@ static inline const void* advance_src(const void* src, size_t elements) {
 // buffer holds the samples from window `first_window` on, only its first `max_windows` windows belong to
 // this part (the samples behind them are the last window's overlap), and the peaks come back unmerged, in
 // window order, at their positions in the whole haystack -- calc_chunks up to audio_matcher.rs:131.
+// Whether the main pass of a haystack with out_count scores leaves its odd last block to a TailPlan -- the conditions
+// run_correlation_one applies, for a caller that computes the tails of several haystacks per launch (match_many).
+static bool haystack_tail(am_needle* h, const Opts& o, long long out_count, TailPlan* t) {
+    t->on = false;
+    Ctx* c = h->ctx;
+    if (needle_is_segmented(h, o) || (h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0)) return false;
+    if (!c->stream_tail || !c->ev_fork || !c->ev_join) return false;
+    Geometry g{};
+    if (plan_geometry(h->n, out_count, o, &g)) return false;
+    return tail_plan(h->n, out_count, o, g, t);   // (main plans of 2^22 points and more: all carry the fused scan)
+}
+// The tails of up to kMaxTailBatch haystacks of a batch (all on one smaller plan) as ONE launch each of K1 / K2 / K3 on
+// the main stream: full grids instead of one under-filled launch triple per haystack beside the main pass (which costs
+// about as much as the dropped pair saves, profiles/r04/tail_block_ab.txt).  The scores and their summary go to slots
+// of the context's tail buffers; launch_tail_commit moves a haystack's slot into the score-side set its pick reads,
+// once the pick that last read that set is done (on the pick's stream).  Same kernels' arithmetic as run_tail_block:
+// a haystack's bits do not depend on whether it travels alone or in a batch.
+struct TailSlots { size_t scores, stats; };   // elements per slot (floats, float2s)
+// (the several-per-launch kernels exist for the 256-row plan, 2^21 points: the tail of a 2^23 main pass that needs the
+// 2^22 plan is computed beside its main pass, like a single haystack's)
+static bool tail_batchable(const TailPlan& t) { return t.on && t.g.logN == 21; }
+static int launch_tail_batch(am_needle* h, const Opts& o, const std::vector<TailPlan>& tails, const std::vector<size_t>& members, int half_idx,
+                             const TailSlots& sl, const void* const* d_hays, const size_t* lens, float factor, int src_kind) {
+    Ctx* c = h->ctx;
+    int rc;
+    const TailPlan& first = tails[members[0]];
+    const Plan* pl = nullptr;
+    if ((rc = get_plan(c, first.g.logN, &pl))) return rc;
+    const float2* hc = nullptr;
+    if ((rc = needle_spectrum(h, pl, &hc))) return rc;
+    const HalfScale hs = half_scale(h, o, pl->dev);
+    if (hs.level == 2 && (rc = needle_spectrum16(h, pl, hs.hscale, &hc))) return rc;
+    TailBatch tb{};
+    tb.n = (int)members.size();
+    for (int j = 0; j < tb.n; ++j) {
+        const size_t k = members[j];
+        const TailPlan& t = tails[k];
+        const size_t slot = (size_t)half_idx * kMaxTailBatch + (size_t)j;
+        tb.src[j] = static_cast<const char*>(d_hays[k]) + 4 * (size_t)t.T;
+        tb.src_len[j] = (long long)lens[k] - t.T;
+        tb.out_count[j] = (long long)(lens[k] - h->n + 1) - t.T;
+        tb.dst[j] = static_cast<float*>(c->tail_scores.p) + slot * sl.scores;
+        tb.stats32[j] = static_cast<float2*>(c->tail_stats.p) + slot * sl.stats;
+    }
+    float2* work = static_cast<float2*>(c->work_tail.p);
+    { ProfScope ps(c, KN_OTHER); AM_HIP(launch_tail_batch_k1(c->stream, tb, (int)first.g.hop, src_kind, work, pl->dev, hs.level)); }
+    { ProfScope ps(c, KN_OTHER); AM_HIP(launch_k2(c->stream, tb.n, work, hc, pl->dev, nullptr, hs.level, hs.hscale, hs.pre, true)); }
+    { ProfScope ps(c, KN_OTHER); AM_HIP(launch_tail_batch_k3(c->stream, tb, (int)first.g.hop, work, pl->dev, hs.k3(factor), hs.level)); }
+    return AM_OK;
+}
+
 struct PartSpec {
     size_t max_windows;
     uint64_t first_sample;            // position of the part's first sample in the whole haystack
@@ -1168,7 +1324,7 @@ struct StreamPre {
 // sample ranges of all block pairs and all windows; rare path, synchronous.
 static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, size_t len, long long out_count,
                               const std::vector<Segment>& segs, int s0, int s1,
-                              std::vector<char>* drop, std::vector<char>* again) {
+                              std::vector<char>* drop, std::vector<char>* again, bool with_tail) {
     Ctx* c = h->ctx;
     const long long s = (long long)h->n;
     const int nch = s1 - s0;
@@ -1177,6 +1333,7 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
     for (int i = s0; i < s1; ++i)       // the samples behind scores [a, b): a .. b + s - 2
         ranges.push_back(Segment{segs[i].a, std::min<long long>((long long)len, segs[i].b + s - 1)});
     Geometry g{};
+    TailPlan tail{};
     long long npairs = 0;
     const bool segmented = needle_is_segmented(h, o);   // (every segment pass has block pairs of its own: all clean windows again)
     if (!segmented && !(h->n <= (size_t)kDirectMaxNeedle && o.log_n == 0)) {   // (direct summation spreads nothing)
@@ -1187,10 +1344,13 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
         // may have been rounded down to a multiple of kTile: pair q reads [2q hop, (2q + 1) hop + N), or
         // [2q hop, 2q hop + N) when its second block does not exist -- up to kTile - 1 samples more than
         // the scores it yields depend on, and a NaN there still poisons the whole pair
+        if (with_tail) tail_plan(h->n, out_count, o, g, &tail);
+        if (tail.on) --npairs;   // (the main pass ends at tail.T; the scores behind it come from one pair of the smaller plan)
         for (long long q = 0; q < npairs; ++q) {
             const long long last_block = (2 * q + 1 < g.nblocks) ? 2 * q + 1 : 2 * q;
             ranges.push_back(Segment{2 * q * g.hop, std::min<long long>((long long)len, last_block * g.hop + g.N)});
         }
+        if (tail.on) ranges.push_back(Segment{tail.T, std::min<long long>((long long)len, tail.T + (tail.g.nblocks - 1) * tail.g.hop + tail.g.N)});
     }
     int rc;
     if ((rc = c->ranges.ensure(sizeof(Segment) * ranges.size()))) return rc;
@@ -1207,6 +1367,7 @@ static int classify_nonfinite(am_needle* h, const Opts& o, const float* d_hay, s
         const Segment sg = segs[s0 + i];
         for (long long q = 0; q < npairs && !(*again)[i]; ++q)
             if (flags[nch + q] && 2 * q * g.hop < sg.b && (2 * q + 2) * g.hop > sg.a) (*again)[i] = 1;
+        if (tail.on && flags[nch + npairs] && tail.T < sg.b) (*again)[i] = 1;
     }
     return AM_OK;
 }
@@ -1301,6 +1462,33 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         if ((rc = correlation_footprint(h, o, (long long)(lens[k] - s + 1), &one))) return rc;
         need.take(one);
     }
+    // The odd last blocks (TailPlan).  A single haystack computes its tail beside its main pass (run_tail_block); a
+    // batch that overlaps picks and transforms computes the tails of up to kMaxTailBatch haystacks per launch, into
+    // slots of two alternating halves (a half is written again two batches later: every commit out of it is long done,
+    // the main stream has waited for the pick of the haystack before the previous one by then).
+    std::vector<TailPlan> tails(n_hay);
+    std::vector<int> tail_slot(n_hay, -1);
+    TailSlots tslots{0, 0};
+    bool batch_tails = false;
+    if (!pre && need.work_tail) {
+        size_t n_tails = 0;
+        for (size_t k = 0; k < n_hay; ++k) {
+            if (n_chunks[k] == 0 || seg_off[k + 1] == seg_off[k]) continue;
+            if (haystack_tail(h, o, (long long)(lens[k] - s + 1), &tails[k]) && tail_batchable(tails[k])) {
+                ++n_tails;
+                tslots.scores = std::max(tslots.scores, (size_t)(2 * tails[k].g.hop));
+            }
+        }
+        tslots.stats = tslots.scores / 32;
+        batch_tails = overlap && n_tails > 1;
+        const size_t nslot = batch_tails ? kMaxTailBatch : 1;
+        if ((rc = c->work_tail.ensure(need.work_tail * nslot))) return rc;
+        if (batch_tails) {
+            if ((rc = c->tail_scores.ensure(2 * kMaxTailBatch * tslots.scores * sizeof(float)))) return rc;
+            if ((rc = c->tail_stats.ensure(2 * kMaxTailBatch * tslots.stats * sizeof(float2)))) return rc;
+        }
+    }
+    int tail_batches = 0;
     for (int set = 0; set < (overlap ? 2 : 1); ++set) {
         if (need.work && (rc = (set ? c->work_b : c->work).ensure(need.work))) return rc;
         if (pre) continue;   // (streaming ingest brings its own summary and flag buffers)
@@ -1393,11 +1581,37 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
             scan.range_b = out_count;
             scan.skip_launch = scan.range_a >= out_count;
         }
+        scan.tail_by_caller = false;
+        if (batch_tails && tail_batchable(tails[k])) {
+            if (tail_slot[k] < 0) {   // the next batch: this haystack and the following ones with such a tail
+                std::vector<size_t> members;
+                for (size_t k2 = k; k2 < n_hay && members.size() < (size_t)kMaxTailBatch; ++k2)
+                    if (tail_batchable(tails[k2]) && tail_slot[k2] < 0) {
+                        tail_slot[k2] = (tail_batches & 1) * kMaxTailBatch + (int)members.size();
+                        members.push_back(k2);
+                    }
+                if ((rc = launch_tail_batch(h, o, tails, members, tail_batches & 1, tslots, d_hays, lens, factor, src_kind))) return rc;
+                ++tail_batches;
+            }
+            scan.tail_by_caller = true;
+        }
         if ((rc = run_correlation(h, o, d_hays[k], (long long)lens[k], 0, d_scores, out_count, factor,
                                   &scan, src_kind))) return rc;
         if (overlap) {
             AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
             AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
+        }
+        if (scan.tail_by_caller && scan.fused) {
+            // (behind the main pass in stream order, hence behind the batch that filled the slot; in front of the pick)
+            const TailPlan& t = tails[k];
+            const size_t tiles = (size_t)1 << (scan.sparse.log_n2 - kColsLog), words = tiles << (scan.sparse.log_n1 - 6);
+            const size_t blk = (size_t)(t.T / scan.sparse.hop);
+            ProfScope ps(c, KN_OTHER, c->stream2);
+            AM_HIP(launch_tail_commit(c->stream2, static_cast<const float*>(c->tail_scores.p) + (size_t)tail_slot[k] * tslots.scores, d_scores + t.T,
+                                      out_count - t.T, static_cast<const float2*>(c->tail_stats.p) + (size_t)tail_slot[k] * tslots.stats,
+                                      const_cast<float2*>(scan.sparse.stats32) + t.T / 32,
+                                      scan.sparse.wbits ? const_cast<unsigned long long*>(scan.sparse.wbits) + blk * words : nullptr, (long long)words,
+                                      scan.sparse.tile_theta ? const_cast<float*>(scan.sparse.tile_theta) + blk * tiles : nullptr, (int)tiles));
         }
         if (scan.fused && scan.sparse.wbits) {
             scan.sparse.fail_flags = h_fail + seg_off[k];
@@ -1426,6 +1640,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
     scan.before_k3 = nullptr;
     scan.bad = nullptr;
     scan.ext_stats32 = nullptr; scan.ext_side = nullptr; scan.side_nblocks = 0; scan.skip_launch = false;   // (the single-chunk passes below work in the context's own buffers)
+    scan.tail_by_caller = false;   // (... and compute a tail they need themselves)
     scan.range_a = 0; scan.range_b = 0;
     int worst = AM_OK;
     std::vector<am_peak> all;
@@ -1465,7 +1680,7 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         // own samples (as the reference does it) and picked from that.
         std::vector<char> drop, again;
         if (h_bad[k]) {
-            if ((rc = classify_nonfinite(h, o, (const float*)d_hays[k], lens[k], out_count, segs, s0, s1, &drop, &again))) return rc;
+            if ((rc = classify_nonfinite(h, o, (const float*)d_hays[k], lens[k], out_count, segs, s0, s1, &drop, &again, pre == nullptr))) return rc;
         }
         // collect in window order (audio_matcher.rs:132-133)
         for (int i = s0; i < s1; ++i) {
@@ -3141,6 +3356,7 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "tail_block")) { g_opt_tail_block = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "k3_group")) { g_opt_k3_group = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "pick_group")) { g_opt_pick_group = value ? 1 : 0; return AM_OK; }
@@ -3174,6 +3390,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
+    if (!strcmp(key, "tail_block")) { *value = g_opt_tail_block; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
     if (!strcmp(key, "k3_group")) { *value = g_opt_k3_group; return AM_OK; }
     if (!strcmp(key, "pick_group")) { *value = g_opt_pick_group; return AM_OK; }

@@ -575,8 +575,7 @@ __device__ __forceinline__ void k1_transform_h16(const K1Twiddles& w, uint2* lds
 }
 
 template <int KIND, int HALF>   // HALF: 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and f16 butterflies
-__global__ void __launch_bounds__(256, 3)
-k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
+__device__ __forceinline__ void k1_cols_fwd_r16_tile(const Job& job, float2* __restrict__ work, const PlanDev& pl) {
     extern __shared__ float4 lds4[];
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
@@ -623,6 +622,22 @@ k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
         store_f4<AM_K1_STORE_NT>(out4 + k1 * (kN2 / 2), make_float4(x0[brev<16>(bp)].x, x0[brev<16>(bp)].y,
                                                                     x1[brev<16>(bp)].x, x1[brev<16>(bp)].y));
     }
+}
+template <int KIND, int HALF>
+__global__ void __launch_bounds__(256, 3)
+k1_cols_fwd_r16(Job job, float2* __restrict__ work, PlanDev pl) {
+    k1_cols_fwd_r16_tile<KIND, HALF>(job, work, pl);
+}
+// The odd last blocks of several haystacks in one launch (TailBatch): entry z = blockIdx.y is pair 0 of its own job
+// and fills work slot z (the tile function takes its slot from blockIdx.y and its pair from first_pair + blockIdx.y).
+template <int KIND, int HALF>
+__global__ void __launch_bounds__(256, 3)
+tail_cols_fwd_r16(TailBatch tb, int hop, float2* __restrict__ work, PlanDev pl) {
+    const unsigned z = blockIdx.y;
+    Job job;
+    job.src = tb.src[z]; job.src_len = tb.src_len[z]; job.lead = 0; job.dst = nullptr; job.out_count = tb.out_count[z];
+    job.hop = hop; job.nblocks = (int)((tb.out_count[z] + hop - 1) / hop); job.first_pair = -(int)z; job.src_kind = KIND;
+    k1_cols_fwd_r16_tile<KIND, HALF>(job, work, pl);
 }
 
 // Ordering point for an LDS exchange whose writers and readers are lanes of the
@@ -877,9 +892,8 @@ constexpr int kK2hLds = 16 * kK2hSlab * 8;     // 34 816 bytes
 #ifndef AM_K2H_WGS
 #define AM_K2H_WGS 3   // waves per SIMD the register allocation has to allow (3 and 4 measure the same; 4 spills)
 #endif
-__global__ void __launch_bounds__(256, AM_K2H_WGS)
-k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
-            float pre) {
+__device__ __forceinline__ void k2_rows_h16_row(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsigned* __restrict__ dst,
+                                                const PlanDev& pl, unsigned npairs, float pre) {
     extern __shared__ float4 lds4[];
     uint2* ldsu = reinterpret_cast<uint2*>(lds4);
     unsigned row, slot;
@@ -985,6 +999,18 @@ k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsi
 #pragma unroll
     for (int a = 0; a < 16; ++a)
         buf_store_u2(rdst, k.voff / 2, a * 2048, make_uint2(h2_bits(x0[brev<16>(a)]), h2_bits(x1[brev<16>(a)])));
+}
+__global__ void __launch_bounds__(256, AM_K2H_WGS)
+k2_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
+            float pre) {
+    k2_rows_h16_row(work, hc16, dst, pl, npairs, pre);
+}
+// (the same kernel for a haystack's odd last block on the smaller plan -- launch_k2(..., tail) -- under a name of its
+// own: a profile's average for k2_rows_h16 stays that of the main pass's launches)
+__global__ void __launch_bounds__(256, AM_K2H_WGS)
+tail_rows_h16(unsigned* __restrict__ work, const unsigned* __restrict__ hc16, unsigned* __restrict__ dst, PlanDev pl, unsigned npairs,
+              float pre) {
+    k2_rows_h16_row(work, hc16, dst, pl, npairs, pre);
 }
 
 // K2 in f32 with the row exchanged one PLANE at a time (the points a thread holds as x0, then those it
@@ -1137,9 +1163,8 @@ __device__ __forceinline__ void k2p_inverse(const PlanDev& pl, float2 (&q)[32], 
 }
 
 template <bool HALF>   // HALF: the work matrix holds __half2 points (half_pipeline = 1), the arithmetic stays f32
-__global__ void __launch_bounds__(256, AM_K2P_WAVES)
-k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst, PlanDev pl, unsigned npairs,
-                   float hscale) {
+__device__ __forceinline__ void k2_rows_r16_planes_row(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst,
+                                                       const PlanDev& pl, unsigned npairs, float hscale) {
     extern __shared__ float4 lds4[];
     float2* lds2 = reinterpret_cast<float2*>(lds4);
     unsigned row, slot;
@@ -1186,6 +1211,18 @@ k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, flo
     scaled(ha);
     k2_multiply_quarter(z, ha, 3, q);
     k2p_inverse<HALF>(pl, q, lds2, rdst);
+}
+template <bool HALF>
+__global__ void __launch_bounds__(256, AM_K2P_WAVES)
+k2_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst, PlanDev pl, unsigned npairs,
+                   float hscale) {
+    k2_rows_r16_planes_row<HALF>(work, hc, dst, pl, npairs, hscale);
+}
+template <bool HALF>   // (a haystack's odd last block: see tail_rows_h16)
+__global__ void __launch_bounds__(256, AM_K2P_WAVES)
+tail_rows_r16_planes(float2* __restrict__ work, const float2* __restrict__ hc, float2* __restrict__ dst, PlanDev pl, unsigned npairs,
+                     float hscale) {
+    k2_rows_r16_planes_row<HALF>(work, hc, dst, pl, npairs, hscale);
 }
 
 // The needle-group kernel (below) on the same plane-by-plane exchanges.
@@ -2049,6 +2086,44 @@ k3_cols_inv_r16_group(Job job, PlanDev pl, ScanCfg scan, K3Group grp) {
     mine.margin = scan.margin; mine.seg_c = scan.seg_c; mine.seg_d = scan.seg_d; mine.inv_c = scan.inv_c;
     mine.only_pairs = nullptr; mine.redo_tiles = 0; mine.edges_n = 0;
     k3_cols_inv_r16_tile<0, false>(blockIdx.x, lds4, job, grp.work[z], pl, grp.out_scale[z], mine, &scan);
+}
+
+// ... and for the odd last blocks of several haystacks (TailBatch): entry z is one pair of a job of its own, every run
+// written, the summary at the place the entry names.
+template <int HALF>
+__global__ void __launch_bounds__(256, AM_K3_WGS)
+tail_cols_inv_r16(TailBatch tb, int hop, const float2* __restrict__ work, PlanDev pl, float out_scale) {
+    extern __shared__ float4 lds4[];
+    const unsigned z = blockIdx.y;
+    Job job;
+    job.src = nullptr; job.src_len = 0; job.lead = 0; job.dst = tb.dst[z]; job.out_count = tb.out_count[z];
+    job.hop = hop; job.nblocks = (int)((tb.out_count[z] + hop - 1) / hop); job.first_pair = 0; job.src_kind = 0;
+    ScanCfg mine;
+    mine.stats32 = tb.stats32[z]; mine.wbits = nullptr; mine.tile_theta = nullptr; mine.margin = -1.0f; mine.hist_min = FLT_MAX;
+    mine.seg_c = 0; mine.seg_d = 0; mine.inv_c = 0.0; mine.only_pairs = nullptr; mine.redo_tiles = 0; mine.edges_n = 0;
+    // (one point of the work matrix is 8 bytes, or 4 with half storage)
+    const float2* mywork = HALF ? reinterpret_cast<const float2*>(reinterpret_cast<const unsigned*>(work) + ((size_t)z << pl.logN))
+                                : work + ((size_t)z << pl.logN);
+    k3_cols_inv_r16_tile<HALF, false>(blockIdx.x, lds4, job, mywork, pl, out_scale, mine);
+}
+
+// A tail's scores and summary into the score-side buffers of its haystack, the main layout's ballots and thresholds
+// of that block to "every run written" (TailBatch; am_api.hip, match_many)
+__global__ void __launch_bounds__(256)
+tail_commit_kernel(const float* __restrict__ tsc, float* __restrict__ sc, long long n, const float2* __restrict__ tst, float2* __restrict__ st32,
+                   unsigned long long* __restrict__ wbits, long long words, float* __restrict__ theta, int tiles) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;   // (both score pointers are 16-byte aligned: the tail starts at a multiple of 1024)
+    const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tsc);
+    float4* __restrict__ s4 = reinterpret_cast<float4*>(sc);
+    for (long long i = tid; i < n4; i += nth) s4[i] = t4[i];
+    for (long long i = (n4 << 2) + tid; i < n; i += nth) sc[i] = tsc[i];
+    const long long n32 = (n + 31) >> 5;
+    for (long long i = tid; i < n32; i += nth) st32[i] = tst[i];
+    if (wbits != nullptr)
+        for (long long i = tid; i < words; i += nth) wbits[i] = ~0ull;
+    if (theta != nullptr)
+        for (long long i = tid; i < tiles; i += nth) theta[i] = -FLT_MAX;
 }
 
 // ===========================================================================
@@ -2928,6 +3003,15 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS(k3_cols_inv_c1024<true>, kC1024Lds)
     AM_SET_LDS(k3_cols_inv_c512_group, kC512Lds)
     AM_SET_LDS(k3_cols_inv_r16_group, kR16LdsK3)
+    AM_SET_LDS(tail_cols_inv_r16<0>, kR16LdsK3)
+    AM_SET_LDS(tail_cols_inv_r16<1>, kR16LdsK3)
+    AM_SET_LDS(tail_cols_inv_r16<2>, kR16LdsK3)
+    AM_SET_LDS((tail_cols_fwd_r16<0, 0>), kR16LdsK1)
+    AM_SET_LDS((tail_cols_fwd_r16<1, 0>), kR16LdsK1)
+    AM_SET_LDS((tail_cols_fwd_r16<0, 1>), kR16LdsK1)
+    AM_SET_LDS((tail_cols_fwd_r16<1, 1>), kR16LdsK1)
+    AM_SET_LDS((tail_cols_fwd_r16<0, 2>), kR16LdsK1)
+    AM_SET_LDS((tail_cols_fwd_r16<1, 2>), kR16LdsK1)
     AM_SET_LDS(k3_cols_inv_c512<0>, kC512Lds)
     AM_SET_LDS((k3_cols_inv_c512<0, true>), kC512Lds)
     AM_SET_LDS((k3_cols_inv_r16<0, true>), kR16LdsK3)
@@ -2941,6 +3025,7 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k2_rows_r16<true, false>), kR16Lds)
     AM_SET_LDS(k2_rows_r16_group, kR16Lds)
     AM_SET_LDS(k2_rows_h16, kK2hLds)
+    AM_SET_LDS(tail_rows_h16, kK2hLds)
     AM_SET_LDS(k2_rows_m16, kK2mLds)
 #undef AM_SET_LDS
     return hipSuccess;
@@ -2991,8 +3076,16 @@ bool k2_mfma_enabled() { return g_k2_mfma.load(std::memory_order_relaxed) != 0; 
 int k2_mfma_table_dwords() { return kMfTotal; }
 
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst,
-                     int half, float hscale, float pre) {
+                     int half, float hscale, float pre, bool tail) {
     const dim3 grid(1u << pl.logN1, npairs);
+    if (tail && plan_k2_is_r16(pl) && AM_K2_PLANES) {
+        const dim3 rows((unsigned)npairs << pl.logN1);
+        if (half == 2) hipLaunchKernelGGL(tail_rows_h16, rows, dim3(256), kK2hLds, st, reinterpret_cast<unsigned*>(work),
+                                          reinterpret_cast<const unsigned*>(hc), reinterpret_cast<unsigned*>(dst), pl, (unsigned)npairs, pre);
+        else if (half) hipLaunchKernelGGL(tail_rows_r16_planes<true>, rows, dim3(256), kK2hLds, st, work, hc, dst, pl, (unsigned)npairs, hscale);
+        else hipLaunchKernelGGL(tail_rows_r16_planes<false>, rows, dim3(256), kK2hLds, st, work, hc, dst, pl, (unsigned)npairs, 1.0f);
+        return hipGetLastError();
+    }
     if (plan_k2_is_r16(pl)) {
         if (half == 2 && k2_mfma_enabled() && pl.mf != nullptr) {
             // persistent workgroups: four per CU walk the rows (the grid stays a multiple of the 8 XCDs)
@@ -3067,6 +3160,30 @@ static void fill_edges(const Job& job, int npairs, ScanCfg& scan) {
 }
 
 bool plan_k3_has_group(const PlanDev& pl) { return plan_is_c512(pl) || plan_is_r16(pl); }
+
+hipError_t launch_tail_batch_k1(hipStream_t st, const TailBatch& tb, int hop, int src_kind, float2* work, const PlanDev& pl, int half) {
+    if (!plan_is_r16(pl) || tb.n < 1 || tb.n > kMaxTailBatch) return hipErrorInvalidValue;
+    const dim3 grid((1u << pl.logN2) >> kColsLog, (unsigned)tb.n);
+#define AM_TAIL_K1(K, H) hipLaunchKernelGGL((tail_cols_fwd_r16<K, H>), grid, dim3(256), kR16LdsK1, st, tb, hop, work, pl)
+    if (src_kind == 1) { if (half == 2) AM_TAIL_K1(1, 2); else if (half) AM_TAIL_K1(1, 1); else AM_TAIL_K1(1, 0); }
+    else { if (half == 2) AM_TAIL_K1(0, 2); else if (half) AM_TAIL_K1(0, 1); else AM_TAIL_K1(0, 0); }
+#undef AM_TAIL_K1
+    return hipGetLastError();
+}
+hipError_t launch_tail_batch_k3(hipStream_t st, const TailBatch& tb, int hop, const float2* work, const PlanDev& pl, float out_scale, int half) {
+    if (!plan_is_r16(pl) || tb.n < 1 || tb.n > kMaxTailBatch) return hipErrorInvalidValue;
+    const dim3 grid(kN2 >> kColsLog, (unsigned)tb.n);
+    if (half == 2) hipLaunchKernelGGL(tail_cols_inv_r16<2>, grid, dim3(256), kR16LdsK3, st, tb, hop, work, pl, out_scale);
+    else if (half) hipLaunchKernelGGL(tail_cols_inv_r16<1>, grid, dim3(256), kR16LdsK3, st, tb, hop, work, pl, out_scale);
+    else hipLaunchKernelGGL(tail_cols_inv_r16<0>, grid, dim3(256), kR16LdsK3, st, tb, hop, work, pl, out_scale);
+    return hipGetLastError();
+}
+hipError_t launch_tail_commit(hipStream_t st, const float* tail_scores, float* scores, long long n, const float2* tail_stats32, float2* stats32,
+                              unsigned long long* wbits, long long words, float* theta, int tiles) {
+    const unsigned grid = (unsigned)std::min<long long>(512, std::max<long long>(1, (n / 4 + 255) / 256));
+    hipLaunchKernelGGL(tail_commit_kernel, dim3(grid), dim3(256), 0, st, tail_scores, scores, n, tail_stats32, stats32, wbits, words, theta, tiles);
+    return hipGetLastError();
+}
 
 hipError_t launch_k3_group(hipStream_t st, const Job& job, int npairs, const K3Group& grp, const PlanDev& pl, const ScanCfg& scan_in) {
     if (!plan_k3_has_group(pl) || grp.n < 1 || grp.n > kMaxNeedleGroup || scan_in.stats32 == nullptr) return hipErrorInvalidValue;

@@ -60,8 +60,10 @@ struct Segment {
 // (K2 and K1 whole; K3's first pass -- its second pass and the score scan stay f32)
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, int half = 0);
 // dst == nullptr: in place; otherwise the result goes to a second work matrix
+// tail: the launch belongs to a haystack's odd last block (am_api.hip, run_tail_block) -- the same row kernels under
+// names of their own (tail_rows_*), so that a profile's per-kernel averages stay those of the main pass
 hipError_t launch_k2(hipStream_t st, int npairs, float2* work, const float2* hc, const PlanDev& pl, float2* dst = nullptr,
-                     int half = 0, float hscale = 1.0f, float pre = 1.0f);
+                     int half = 0, float hscale = 1.0f, float pre = 1.0f, bool tail = false);
 // half = 2: hc points at the __half2 form of the spectrum (launch_spectrum_to_half), hscale already in it
 hipError_t launch_spectrum_to_half(hipStream_t st, const float2* hc, long long n, float scale, unsigned* out);
 // option "k2_mfma" (an A/B experiment for half_pipeline = 2): the row kernel's butterflies on the matrix cores;
@@ -125,6 +127,25 @@ struct K3Group {
     float out_scale[kMaxNeedleGroup];
 };
 bool plan_k3_has_group(const PlanDev& pl);
+// The odd last blocks of several haystacks of a batch (am_api.hip, TailPlan) as ONE launch each of K1 / K2 / K3 on the
+// 256-row plan: entry z = blockIdx.y is one block pair of a job of its own (source, scores, summary), work slot z.
+// Every run of raw scores is written (no ballots, no thresholds).
+constexpr int kMaxTailBatch = 8;
+struct TailBatch {
+    int n;
+    const void* src[kMaxTailBatch];      // the haystack's samples from the tail's first score on
+    long long src_len[kMaxTailBatch];
+    float* dst[kMaxTailBatch];           // out_count scores
+    long long out_count[kMaxTailBatch];
+    float2* stats32[kMaxTailBatch];      // their level-0 summary
+};
+// hop, src_kind: shared by the entries (one needle, one sample format)
+hipError_t launch_tail_batch_k1(hipStream_t st, const TailBatch& tb, int hop, int src_kind, float2* work, const PlanDev& pl, int half);
+hipError_t launch_tail_batch_k3(hipStream_t st, const TailBatch& tb, int hop, const float2* work, const PlanDev& pl, float out_scale, int half);
+// A tail's scores and summary into the score-side buffers the pick reads, and the main layout's ballots / thresholds of
+// the block they belong to set to "every run written" (one small launch on the pick's stream)
+hipError_t launch_tail_commit(hipStream_t st, const float* tail_scores, float* scores, long long n, const float2* tail_stats32, float2* stats32,
+                              unsigned long long* wbits, long long words, float* theta, int tiles);
 hipError_t launch_k3_group(hipStream_t st, const Job& job, int npairs, const K3Group& grp, const PlanDev& pl, const ScanCfg& scan);
 // needles of at most this many samples are correlated by direct summation (no transform)
 constexpr int kDirectMaxNeedle = 64;

@@ -67,9 +67,11 @@ def shard(n_items: int, rank: int, world: int):
     return sharding.shard_indices(n_items, rank, world)
 
 
-def plan_geometry(s: int, h: int, log_n: int = 0):
+def plan_geometry(s: int, h: int, log_n: int = 0, tail_block: int = 0):
     """The library's block layout for a needle of s samples and a haystack of h (am_api.hip pick_log_n /
-    plan_geometry): transform length, hop, blocks, pairs."""
+    plan_geometry / tail_plan): transform length, hop, blocks, pairs of the main pass and -- option tail_block, single-needle
+    calls -- the transform length of the smaller plan an odd last block goes through (0: none)."""
+    forced = bool(log_n)
     if not log_n:
         log_n = 21 if s <= 140000 else 22
         hop21 = (2 ** 21 - s + 1) // 1024 * 1024
@@ -81,7 +83,16 @@ def plan_geometry(s: int, h: int, log_n: int = 0):
         hop = hop // 1024 * 1024
     out_count = h - s + 1
     nblocks = -(-out_count // hop)
-    return {"log_n": log_n, "n_fft": n_fft, "hop": hop, "out_count": out_count, "nblocks": nblocks, "npairs": (nblocks + 1) // 2}
+    npairs, tail_n_fft = (nblocks + 1) // 2, 0
+    if tail_block and not forced and log_n >= 22 and nblocks % 2 == 1 and nblocks >= 3 and hop % 1024 == 0:
+        rest = out_count - (nblocks - 1) * hop
+        for lt in range(21, log_n):
+            hop_t = (2 ** lt - s + 1) // 1024 * 1024
+            if hop_t >= 8192 and 2 * hop_t >= rest:
+                npairs, tail_n_fft = npairs - 1, 2 ** lt
+                break
+    return {"log_n": log_n, "n_fft": n_fft, "hop": hop, "out_count": out_count, "nblocks": nblocks, "npairs": npairs,
+            "tail_n_fft": tail_n_fft}
 
 
 # ---------------------------------------------------------------------------
@@ -95,6 +106,7 @@ class Workload:
     default_batch = 8
     dominant = "k2_rows"
     dtype = "f32"
+    tail_block = True      # the engine of this workload sends a haystack's odd last block through the smaller plan
 
     def __init__(self, am, device, args):
         self.am, self.device, self.args = am, device, args
@@ -102,7 +114,7 @@ class Workload:
         self.hay_bytes = 4 * self.h          # an f32 sample and an i16 stereo frame are both 4 bytes
         cfg = am.Config(chunk_size_s=CHUNK_S, overlap_length_s=NEEDLE_S, distance_s=480.0, prominence=0.13)
         self.params = cfg.params(self.sr, am.Scale.LIB)
-        self.geo = plan_geometry(self.s, self.h, am.get_option("log_n") or 0)
+        self.geo = plan_geometry(self.s, self.h, am.get_option("log_n") or 0, am.get_option("tail_block") if self.tail_block else 0)
 
     # -- config 2: one f32 needle ---------------------------------------------------------------
     def setup(self):
@@ -125,9 +137,9 @@ class Workload:
     def units_per_haystack(self):
         return float(self.h) * self.n_needles
 
-    def kernel_bytes(self, dense=False):
+    def kernel_bytes(self, dense=False, main_only=False):
         g = self.geo
-        pts = g["npairs"] * g["n_fft"]
+        pts = g["npairs"] * g["n_fft"] + (0 if main_only else g["tail_n_fft"])
         # one point of the work matrix: a float2, or a half2 with --half-pipeline 1 / 2
         pt = 4 if self.am.get_option("half_pipeline") else 8
         spec = 4 if self.am.get_option("half_pipeline") >= 2 else 8   # (level 2 multiplies with an f16 copy of the spectrum)
@@ -135,13 +147,14 @@ class Workload:
             "k1_cols_fwd": pts * (8 + pt),                     # two f32 blocks in, one complex point out
             # complex in, complex out; the needle spectrum (one transform's worth) is shared by all
             # pairs through L2 and has to come from HBM once per launch, not once per pair
-            "k2_rows": pts * (pt + pt) + g["n_fft"] * spec,
+            "k2_rows": pts * (pt + pt) + g["n_fft"] * spec + (0 if main_only else g["tail_n_fft"] * spec),
             # complex in, (min,max) per 32 scores out; raw scores only where the pick can need them
             "k3_cols_inv": pts * pt + (g["out_count"] // 32) * 8 + (g["out_count"] * 4 if dense else 0),
         }
 
     def dominant_bytes_per_launch(self):
-        return self.kernel_bytes()[self.dominant]
+        # (the main pass's launch: the tail block's three launches are profiled apart, under "other" / tail_rows_*)
+        return self.kernel_bytes(main_only=True)[self.dominant]
 
     def launches_per_haystack(self):
         return 1
@@ -159,6 +172,7 @@ class MultiNeedleWorkload(Workload):
     config = 3
     n_needles = 32
     default_batch = 2
+    tail_block = False     # (the several-needle engine keeps the odd last block as half of a full pair)
 
     def setup(self):
         am = self.am
@@ -184,7 +198,7 @@ class MultiNeedleWorkload(Workload):
         for j, r in enumerate(res):
             assert [p.start for p in r] == self.plants(k, j), (k, j, r)
 
-    def kernel_bytes(self, dense=False):
+    def kernel_bytes(self, dense=False, main_only=False):
         g = self.geo
         pts = g["npairs"] * g["n_fft"]
         nn = self.n_needles
@@ -234,12 +248,12 @@ class Pcm16HalfWorkload(Workload):
     def match(self, ptrs):
         return self.algo.match_pcm16_batch_device(ptrs, [self.h] * len(ptrs), self.params, cap_per_hay=16)
 
-    def kernel_bytes(self, dense=False):
+    def kernel_bytes(self, dense=False, main_only=False):
         g = self.geo
-        pts = g["npairs"] * g["n_fft"]
+        pts = g["npairs"] * g["n_fft"] + (0 if main_only else g["tail_n_fft"])
         return {
             "k1_cols_fwd": pts * (8 + 4),          # two i16 stereo frames in (4 B each), one half2 point out
-            "k2_rows": pts * (4 + 4) + g["n_fft"] * 4,
+            "k2_rows": pts * (4 + 4) + g["n_fft"] * 4 + (0 if main_only else g["tail_n_fft"] * 4),
             "k3_cols_inv": pts * 4 + (g["out_count"] // 32) * 8 + (g["out_count"] * 4 if dense else 0),
         }
 
@@ -566,7 +580,8 @@ def main():
         if R.rank == 0:
             # rank 0's K2: its part's block pairs go through the row kernel in launches of at most `pairs_per_group`
             # pairs (each launch reads the needle spectrum once): bytes of all launches of a step over their time
-            g = plan_geometry(s, parts[0]["samples"], am.get_option("log_n") or 0) if parts[0]["samples"] >= s else None
+            g = plan_geometry(s, parts[0]["samples"], am.get_option("log_n") or 0, am.get_option("tail_block")) \
+                if parts[0]["samples"] >= s else None   # (npairs: the main pass's; a tail block is profiled under "other")
             ppg = am.get_option("pairs_per_group")
             launches_per_step = -(-g["npairs"] // ppg) if g else 1
             dom_bytes = ((g["npairs"] * g["n_fft"] * 16 + launches_per_step * g["n_fft"] * 8) / launches_per_step) if g else 0
@@ -701,6 +716,7 @@ def main():
                    "baseline_config": args.config, "needles": W.n_needles,
                    "needle_samples": s, "haystack_samples": h, "haystacks_per_rank_per_step": hay_per_rank_step,
                    "fft_log2": geo["log_n"], "hop": geo["hop"], "block_pairs_per_haystack": geo["npairs"],
+                   "tail_block_fft_log2": (geo["tail_n_fft"].bit_length() - 1) if geo["tail_n_fft"] else None,
                    "ramp_steps": args.ramp_steps, "timed_region_ms": timed_ms,
                    "ranks": R.world, "devices_used": devices_used, "devices_visible_per_rank": ndev, "ranks_per_device": rpd,
                    "per_rank_seconds": per_rank,

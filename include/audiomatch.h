@@ -375,6 +375,13 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *   "dense_scores" (0/1): write every raw score from the inverse pass (threshold -inf)
  *       instead of only the tiles that can matter to the peak pick; results are
  *       identical, this is the worst case of the sparse-score path for measurements.
+ *   "tail_block" (0/1, default 1): two overlap-save blocks share one complex transform, so a haystack with an odd
+ *       number of blocks pays a whole pair for its last, part-filled block.  1 = when the scores behind the last even
+ *       block boundary fit one pair of the next smaller transform (half the points), they come from that: beside the
+ *       main pass for a single haystack, several haystacks per launch in a batch.  Offsets are unaffected, scores agree
+ *       to rounding (1e-6); a haystack's results do not depend on the batch it travels in.  Single-needle entry points
+ *       (am_match*, am_pool_match_batch*, am_pool_match_long*, am_match_part_device); not the several-needle engine,
+ *       not streaming ingest, not a forced "log_n".
  *   "device_redo" (0/1, default 1): in a batch, chunks whose sparse-score certificate fails get their dense
  *       inverse pass on the device, beside the next haystack's transforms; 0 = the host path does it
  *       after the call's kernels (results are identical; for measurements).

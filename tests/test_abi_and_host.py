@@ -194,9 +194,17 @@ def test_bench_workloads_state_their_design_bytes():
     sys.path.insert(0, ROOT)
     import bench
     g = bench.plan_geometry(441000, 158760000)
-    assert g == {"log_n": 22, "n_fft": 1 << 22, "hop": 3752960, "out_count": 158319001, "nblocks": 43, "npairs": 22}
+    assert g == {"log_n": 22, "n_fft": 1 << 22, "hop": 3752960, "out_count": 158319001, "nblocks": 43, "npairs": 22, "tail_n_fft": 0}
     g4 = bench.plan_geometry(480000, 172800000)
     assert g4["npairs"] == 24 and g4["hop"] == 3714048 and g4["nblocks"] == 47
+    # the odd last block on the smaller plan (option tail_block): 21 / 23 main pairs and one pair of the 2^21 plan
+    gt = bench.plan_geometry(441000, 158760000, tail_block=1)
+    assert (gt["npairs"], gt["tail_n_fft"], gt["nblocks"]) == (21, 1 << 21, 43)
+    gt4 = bench.plan_geometry(480000, 172800000, tail_block=1)
+    assert (gt4["npairs"], gt4["tail_n_fft"]) == (23, 1 << 21)
+    assert bench.plan_geometry(441000, 158760000 + 3752960, tail_block=1)["tail_n_fft"] == 0          # 44 blocks: nothing odd
+    assert bench.plan_geometry(441000, 42 * 3752960 + 441000 + 3400000, tail_block=1)["tail_n_fft"] == 0   # more than one 2^21 pair holds
+    assert bench.plan_geometry(441000, 158760000, 22, tail_block=1)["tail_n_fft"] == 0                   # a forced plan is taken as it is
 
 
 def test_isa_has_no_store_data_hazard(tmp_path):

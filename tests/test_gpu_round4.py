@@ -491,3 +491,152 @@ def test_matrix_core_row_kernel_is_result_equivalent(gpu, oracle):
     finally:
         gpu.set_option("k2_mfma", 0)
     assert gpu.get_option("k2_mfma") == 0
+
+
+# ---------------------------------------------------------------------------
+# the odd last block on the smaller plan (option tail_block, on by default)
+# ---------------------------------------------------------------------------
+def tail_geometry(s):
+    """Hops of the 2^22 plan and of the 2^21 plan for a needle of s samples (am_api.hip, plan_geometry)."""
+    hop = ((1 << 22) - s + 1) // 1024 * 1024
+    hop_t = ((1 << 21) - s + 1) // 1024 * 1024
+    return hop, hop_t
+
+
+def tail_case(oracle, sr, s, rest, seed, where, even_blocks=2):
+    """A haystack of `even_blocks` blocks of the 2^22 plan + `rest` scores (an odd last block: with the option on, scores
+    [T, T + rest) come from one pair of the 2^21 plan), hits planted at the score positions where(T, hop_t, out)."""
+    hop, hop_t = tail_geometry(s)
+    T = even_blocks * hop
+    out = T + rest
+    needle = oracle.synth_uniform(seed, 0, 0, s)
+    hay = oracle.synth_uniform(seed, 1, 0, out + s - 1)
+    offs = sorted(where(T, hop_t, out))
+    for off in offs:
+        hay[off:off + s] += needle
+    return needle, hay, offs, T
+
+
+def test_odd_last_block_on_the_smaller_plan(gpu, oracle):
+    """10 s needle (the 2^22 plan), haystacks with an odd, part-filled last block: with tail_block = 1 (default) the main
+    pass stops at the even block boundary T and the scores behind it come from one pair of the 2^21 plan, every run
+    written -- beside the main pass for a single haystack, several haystacks' tails per launch in a batch.  Hits right
+    before T, on the first tail scores, on either side of the tail's own block boundary and on the last scores:
+    offsets == checker, heights within 1e-4, the same with the option off (the last block as half of a full pair);
+    the launch counts (the tail's kernels are profiled as "other") say which form ran; and a haystack's results are
+    the same bit for bit alone and in any batch, although a batch computes its tails several per launch."""
+    sr = 44100
+    s = 10 * sr
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=2.0, prominence=0.3).params(sr, gpu.Scale.LIB)
+    cases = [tail_case(oracle, sr, s, 1900000, 201, lambda T, ht, out: [sr + 7, T - 5, T + ht - 2, out - 3]),   # two tail blocks
+             tail_case(oracle, sr, s, 1900000, 202, lambda T, ht, out: [T + 3, T + ht + 1, out - 3]),
+             tail_case(oracle, sr, s, 500000, 203, lambda T, ht, out: [T - 3 * sr, T, out - 2]),               # one tail block
+             tail_case(oracle, sr, s, 2 * tail_geometry(s)[1], 204, lambda T, ht, out: [T + ht - 1, out - 2]),  # the most that fits
+             tail_case(oracle, sr, s, 1900000, 206, lambda T, ht, out: [T - 2 * sr, T + 7, out - 3], even_blocks=4)]
+    even = oracle.synth_uniform(205, 1, 0, 3 * tail_geometry(s)[0] + 1000 + s)                              # four blocks: no tail
+    gpu.set_option("profile_mask", -1)
+    algo = gpu.HipConvolve(cases[0][0])
+    try:
+        for needle, hay, offs, T in cases:
+            a = gpu.HipConvolve(needle)
+            exp = oracle.calc_chunks(sr, hay, needle, p.chunk, p.overlap, 0.3, p.min_distance, 2.0)
+            assert [e[0] for e in exp] == offs
+            buf = gpu.DeviceBuffer.from_numpy(0, hay)
+            res, launches = {}, {}
+            for on in (1, 0):
+                gpu.set_option("tail_block", on)
+                a.match_device(buf.ptr, hay.size, p)            # (plans and spectra exist from here on)
+                with gpu.Profile(0) as prof:
+                    res[on] = a.match_device(buf.ptr, hay.size, p)
+                    launches[on] = (prof.query("k1_cols_fwd")[1], prof.query("other")[1])
+                assert_same(res[on], exp)
+            assert launches[1][0] == launches[0][0] == 1 and launches[1][1] == launches[0][1] + 3
+            assert_close_peaks(res[1], res[0], tol=1e-5)
+            a.close()
+        # bit-identical alone and in a batch (same needle for all: the first case's), and the batch's tails really
+        # went several per launch: three launches and one commit per haystack with a tail, not three per haystack
+        gpu.set_option("tail_block", 1)
+        hays = [c[1] for c in cases[:2]] + [even, cases[2][1], cases[4][1]]
+        bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in hays]
+        want = [key(algo.match_device(b.ptr, h.size, p)) for b, h in zip(bufs, hays)]
+        for order in ([0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [0, 0, 2, 0, 3, 3, 1, 4, 4, 1, 0, 3, 1]):
+            ptrs, lens = [bufs[i].ptr for i in order], [hays[i].size for i in order]
+            algo.match_batch_device(ptrs, lens, p)
+            with gpu.Profile(0) as prof:
+                got = algo.match_batch_device(ptrs, lens, p)
+                other = prof.query("other")[1]
+            assert [key(r) for r in got] == [want[i] for i in order], order
+            with_tail = sum(1 for i in order if i != 2)
+            assert other == 3 * -(-with_tail // 8) + with_tail, (order, other)
+    finally:
+        gpu.set_option("tail_block", 1)
+        algo.close()
+    assert gpu.get_option("tail_block") == 1
+
+
+def test_odd_last_block_redo_nan_and_half_paths(gpu, oracle):
+    """The rare paths around the tail block: (a) a chunk that reaches into the tail fails its certificate (a dip
+    deeper than half a prominence) -- redone from the host in a single call (the redo recomputes the tail as well: the
+    score buffers have moved on) and on the device in a batch; (b) a NaN sample that only the tail's transform reads:
+    its window yields nothing, the clean window whose last scores came from the poisoned tail pair is correlated again
+    on its own -- alone and in a batch; (c) the packed-f16 pipeline on i16 stereo frames: same offsets with the option
+    on and off, alone and in a batch."""
+    sr = 44100
+    s = 10 * sr
+    hop, hop_t = tail_geometry(s)
+    T = 2 * hop
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=2.0, prominence=0.13).params(sr, gpu.Scale.LIB)
+    needle, hay, offs, _ = tail_case(oracle, sr, s, 1900000, 211, lambda T, ht, out: [20 * sr, T + 3 * sr, out - 1 - sr])
+    assert gpu.get_option("tail_block") == 1
+    # (a) dips in the chunk that holds T and in the last chunk
+    dipped = hay.copy()
+    for off in (T - 4 * sr - s, T + 12 * sr):
+        dipped[off:off + s] -= needle
+    exp = oracle.calc_chunks(sr, dipped, needle, p.chunk, p.overlap, 0.13, p.min_distance, 2.0)
+    assert [e[0] for e in exp] == offs
+    algo = gpu.HipConvolve(needle)
+    buf = gpu.DeviceBuffer.from_numpy(0, dipped)
+    clean = gpu.DeviceBuffer.from_numpy(0, hay)
+    try:
+        one = algo.match_device(buf.ptr, dipped.size, p)
+        assert_same(one, exp)
+        for arm in (-1, 0):
+            gpu.set_option("debug_redo_arm_at", arm)
+            got = algo.match_batch_device([buf.ptr, clean.ptr, buf.ptr], [dipped.size, hay.size, dipped.size], p)
+            assert key(got[0]) == key(got[2]) == key(one), arm
+            assert [q.start for q in got[1]] == offs
+    finally:
+        gpu.set_option("debug_redo_arm_at", -2)
+    # (b) a NaN near the end: behind everything the main pass reads (block 1 ends at hop + 2^22)
+    bad = hay.copy()
+    at = hay.size - 1000
+    assert at > hop + (1 << 22)
+    bad[at] = np.nan
+    exp = oracle.calc_chunks(sr, bad, needle, p.chunk, p.overlap, 0.13, p.min_distance, 2.0)
+    assert [e[0] for e in exp] == offs[:2]          # the last window holds the NaN: its hit is gone, T + 3 s (previous window) stays
+    alone = algo.match(bad, p)
+    assert_same(alone, exp)
+    badbuf = gpu.DeviceBuffer.from_numpy(0, bad)
+    got = algo.match_batch_device([clean.ptr, badbuf.ptr, clean.ptr], [hay.size, bad.size, hay.size], p)
+    assert key(got[1]) == key(alone) and [q.start for q in got[0]] == [q.start for q in got[2]] == offs
+    algo.close()
+    # (c) i16 stereo, half_pipeline = 2
+    def stereo(x):
+        q = np.clip(np.round(x * 12000.0), -32768, 32767).astype(np.int16)
+        return np.ascontiguousarray(np.stack([q, q], axis=1))
+    ha = gpu.HipConvolve.from_pcm16(stereo(needle))
+    ha.set_option("half_pipeline", 2)
+    frames = stereo(hay)
+    fbuf = gpu.DeviceBuffer.from_numpy(0, frames)
+    res = {}
+    try:
+        for on in (1, 0):
+            gpu.set_option("tail_block", on)
+            res[on] = ha.match_pcm16(frames, p)
+            assert [q.start for q in res[on]] == offs
+            both = ha.match_pcm16_batch_device([fbuf.ptr, fbuf.ptr], [hay.size, hay.size], p)
+            assert key(both[0]) == key(both[1]) == key(res[on]), on
+        assert_close_peaks(res[1], res[0], tol=2e-3)
+    finally:
+        gpu.set_option("tail_block", 1)
+        ha.close()
