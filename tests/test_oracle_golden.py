@@ -62,6 +62,21 @@ def test_pcm_downmix_bits(oracle):
     assert [int(v) for v in got.view(np.uint32)] == k["expected_f32_bits"]
 
 
+def test_pcm_downmix_in_three_steps_has_the_same_bits(oracle):
+    """The kernels form (l + r) as an integer, convert once and multiply once with half the constant
+    (am_fft.hip, downmix_s16) where mp3_reader.rs:12, 28-37 converts both, adds and multiplies twice: the same f32
+    bits for every sum l + r there is (the checker implements the reference's order)."""
+    sums = np.arange(-65536, 65535, dtype=np.int64)
+    lr = np.empty((sums.size, 2), np.int16)
+    lr[:, 0] = np.clip(sums, -32768, 32767)
+    lr[:, 1] = sums - lr[:, 0].astype(np.int64)
+    assert np.array_equal(lr.astype(np.int64).sum(axis=1), sums)
+    ref = oracle.pcm_s16_stereo_to_mono(np.ascontiguousarray(lr).reshape(-1))
+    c = np.float32(0.5) * (np.float32(1.0) / np.float32(65535.0))
+    fused = sums.astype(np.float32) * c
+    assert fused.dtype == np.float32 and np.array_equal(fused.view(np.uint32), ref.view(np.uint32))
+
+
 def test_modes_are_crops_of_full(oracle):
     rng = np.random.default_rng(0)
     for w, s in [(20, 3), (64, 64), (100, 37), (5, 9)]:
