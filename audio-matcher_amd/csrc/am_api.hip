@@ -286,6 +286,7 @@ static void prof_harvest(Ctx* c) {
     if (c->pending.empty()) return;
     (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream_tail) (void)hipStreamSynchronize(c->stream_tail);
     for (auto& r : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { c->prof_ms[r.name] += ms; c->prof_n[r.name] += 1; }
@@ -2853,6 +2854,7 @@ int am_shutdown(void) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        if (c->stream_tail) (void)hipStreamSynchronize(c->stream_tail);
         for (DevBuf* b : {&c->work, &c->work2, &c->scores, &c->stats, &c->stats32, &c->wflags, &c->segs,
                           &c->scores_b, &c->stats_b, &c->stats32_b, &c->wflags_b, &c->peaks_b, &c->work_b, &c->redo_pairs[0], &c->redo_pairs[1],
                           &c->peaks, &c->io_in, &c->io_out, &c->sum, &c->arena_cur, &c->wide_ctl, &c->wide_list, &c->wide_tiles})
@@ -2863,6 +2865,7 @@ int am_shutdown(void) {
         if (c->badflag.p) { (void)hipHostFree(c->badflag.p); c->badflag.p = nullptr; c->badflag.cap = 0; }
         if (c->failcnt.p) { (void)hipHostFree(c->failcnt.p); c->failcnt.p = nullptr; c->failcnt.cap = 0; }
         c->ranges.release(); c->range_flags.release(); c->big.release();
+        c->work_tail.release(); c->tail_scores.release(); c->tail_stats.release();
         for (int i = 0; i < 2 * kMaxNeedleGroup; ++i) { c->grp_scores[i].release(); c->grp_stats32[i].release(); c->grp_wflags[i].release(); }
         for (int i = 0; i < kMaxNeedleGroup; ++i) c->grp_stats[i].release();
         c->segs_resident.clear();
