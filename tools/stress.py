@@ -7,6 +7,11 @@
                                           one-pair problems of every plan family (whole working
                                           set in the L2s): a stale line or a lost store between
                                           kernels shows as pieces of the other input's data
+  stress.py tail [iters]                  ragged batches of haystacks with and without an odd last
+                                          block (option tail_block: tails several per launch, copied
+                                          into the score sets on the pick's stream), dips that fail
+                                          certificates in the tail's chunk, device redo armed; every
+                                          batch result compared with the single calls'
 """
 import ctypes as C
 import os
@@ -51,9 +56,46 @@ def alternate(iters):
         print("%-22s %d iterations, %d mismatches" % (name, iters, bad), flush=True)
 
 
+def tails(iters):
+    rng = np.random.default_rng(5)
+    s = S
+    hop = ((1 << 22) - s + 1) // 1024 * 1024
+    needle = am.synth_uniform_device(0, s, seed=3, stream=0)
+    algo = am.HipConvolve.from_device(0, needle.ptr, s)
+    p = am.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=2.0, prominence=0.13).params(SR, am.Scale.LIB)
+    key = lambda r: [(q.start, q.end, q.height, q.prominence) for q in r]
+    hays, lens = [], []
+    for k, (blocks, rest) in enumerate([(2, 700000), (4, 1900000), (3, 2000000), (6, 3000000), (2, 3311616), (4, 100), (8, 1234567), (5, 50000)]):
+        out = blocks * hop + rest if blocks % 2 == 0 else (blocks - 1) * hop + rest + hop      # odd `blocks`: an even block count
+        n = out + s - 1
+        b = am.synth_uniform_device(0, n, seed=3, stream=k + 1)
+        for t in (7 * SR + k, out - 1 - 3 * SR - k, (blocks - blocks % 2) * hop + 5):
+            am.axpy_device(0, b, t, needle.ptr, s, 1.0)
+        if k % 3 == 0:                                                                       # a dip in the last chunk
+            am.axpy_device(0, b, out - 1 - 20 * SR, needle.ptr, s, -1.0)
+        hays.append(b); lens.append(n)
+    want = [key(algo.match_device(b.ptr, n, p)) for b, n in zip(hays, lens)]
+    print("single calls:", [len(w) for w in want], flush=True)
+    bad = 0
+    for it in range(iters):
+        order = list(rng.permutation(len(hays))) + list(rng.integers(0, len(hays), size=int(rng.integers(0, 9))))
+        am.set_option("debug_redo_arm_at", int(rng.integers(-2, 3)))
+        res = algo.match_batch_device([hays[i].ptr for i in order], [lens[i] for i in order], p)
+        for j, i in enumerate(order):
+            if key(res[j]) != want[i]:
+                bad += 1
+                print("iter %d: haystack %d at place %d of %s differs: %s != %s" % (it, i, j, order, key(res[j]), want[i]), flush=True)
+        if it % 20 == 0:
+            print("iter", it, "bad so far", bad, flush=True)
+    am.set_option("debug_redo_arm_at", -2)
+    print("done: %d batches, %d mismatches" % (iters, bad))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "alt":
         return alternate(int(sys.argv[2]) if len(sys.argv) > 2 else 300)
+    if len(sys.argv) > 1 and sys.argv[1] == "tail":
+        return tails(int(sys.argv[2]) if len(sys.argv) > 2 else 100)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     mix = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     for kv in sys.argv[3:]:
