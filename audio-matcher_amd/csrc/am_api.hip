@@ -66,6 +66,7 @@ static Hooks snapshot_hooks() {
 static std::atomic<long long> g_opt_log_n{0};            // 0 = auto
 static std::atomic<long long> g_opt_pairs_per_group{64};
 static std::atomic<long long> g_opt_profile_mask{-1};    // bit i = bracket kernel class i with events while profiling is on
+static std::atomic<long long> g_opt_profile_every{1};    // ... every n-th launch of the class only (an event pair costs the stream about 8 us per kernel boundary)
 static std::atomic<long long> g_opt_half{0};             // 1 = half-precision storage of the work matrix (config 5)
 static std::atomic<long long> g_opt_batch_overlap{1};    // 1 = in a batch, pick the peaks of haystack k beside the transforms of k+1
 static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one forward row transform in am_match_multi_device
@@ -216,8 +217,19 @@ struct Ctx {
     std::vector<hipEvent_t> pool;
     double prof_ms[KN_COUNT] = {0};
     uint64_t prof_n[KN_COUNT] = {0};
+    uint64_t prof_seq[KN_COUNT] = {0};   // launches of the class seen while profiling is on (option profile_every)
 };
 
+// Events that order the library's streams of ONE device among themselves (the pick behind K3, K3 behind the pick that
+// last read its score set, the tail stream) and the events that time kernels: without the system-scope fence a default
+// event performs when it is recorded -- a write-back and invalidation of the caches that the next kernel then pays
+// for (a kernel boundary with such an event in it measured 8 us, one without 1.8 us: profiles/r04/event_fence_ab.txt).
+// Kernel boundaries order device memory by themselves; what the host reads (result headers in pinned memory) it reads
+// behind a hipStreamSynchronize.
+#ifndef AM_EVENT_NO_SYSTEM_FENCE
+#define AM_EVENT_NO_SYSTEM_FENCE 1
+#endif
+static const unsigned kSyncEvent = hipEventDisableTiming | (AM_EVENT_NO_SYSTEM_FENCE ? hipEventDisableSystemFence : 0u);
 static std::mutex g_ctx_mu;
 static std::map<int, Ctx*> g_ctx;
 
@@ -252,12 +264,12 @@ static int get_ctx(int device, Ctx** out) {
         (void)hipGetLastError();
     }
     (void)hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_fork, kSyncEvent);
+    (void)hipEventCreateWithFlags(&c->ev_join, kSyncEvent);
     (void)hipGetLastError();
     for (int i = 0; i < 2; ++i) {
-        (void)hipEventCreateWithFlags(&c->ev_k3[i], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&c->ev_pick[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&c->ev_k3[i], kSyncEvent);
+        (void)hipEventCreateWithFlags(&c->ev_pick[i], kSyncEvent);
     }
     g_ctx[device] = c;
     *out = c;
@@ -268,7 +280,7 @@ static int get_ctx(int device, Ctx** out) {
 static hipEvent_t prof_event(Ctx* c) {
     if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    (void)hipEventCreateWithFlags(&e, AM_EVENT_NO_SYSTEM_FENCE ? hipEventDisableSystemFence : hipEventDefault);   // (timing only: see kSyncEvent)
     return e;
 }
 struct ProfScope {
@@ -276,6 +288,10 @@ struct ProfScope {
     bool on;
     ProfScope(Ctx* c_, int name_, hipStream_t st_ = nullptr) : c(c_), name(name_), st(st_ ? st_ : c_->stream) {
         on = c->prof && ((g_opt_profile_mask.load(std::memory_order_relaxed) >> name) & 1);
+        if (on) {
+            const long long every = std::max<long long>(1, g_opt_profile_every.load(std::memory_order_relaxed));
+            on = (c->prof_seq[name]++ % (uint64_t)every) == 0;
+        }
         if (on) { e0 = prof_event(c); e1 = prof_event(c); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
@@ -3358,6 +3374,7 @@ int am_set_option(const char* key, long long value) {
     }
     if (!strcmp(key, "half_pipeline")) { g_opt_half = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { g_opt_batch_overlap = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "profile_every")) { g_opt_profile_every = value < 1 ? 1 : value; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "tail_block")) { g_opt_tail_block = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
@@ -3392,6 +3409,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "half_pipeline")) { *value = g_opt_half; return AM_OK; }
     if (!strcmp(key, "needle_group")) { *value = g_opt_needle_group; return AM_OK; }
     if (!strcmp(key, "batch_overlap")) { *value = g_opt_batch_overlap; return AM_OK; }
+    if (!strcmp(key, "profile_every")) { *value = g_opt_profile_every; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "tail_block")) { *value = g_opt_tail_block; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }

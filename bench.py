@@ -346,6 +346,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the dense / non-white / host-buffer side measurements")
     ap.add_argument("--cpu-chunks", type=int, default=0, help="chunks in the CPU sample (0 = three per thread, at most the whole hour)")
+    ap.add_argument("--profile-every", type=int, default=5,
+                    help="the timed region brackets every n-th launch of the dominant kernel with HIP events (an event pair costs "
+                         "the stream about 8 us per kernel boundary: bracketing all of them takes 2 %% off the headline)")
     ap.add_argument("--log-n", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (experiments)")
     ap.add_argument("--half-pipeline", type=int, nargs="?", const=1, default=0,
@@ -627,9 +630,13 @@ def main():
         for _ in range(args.warmup):
             check(step())
         # Timed region: HIP events bracket only the dominant kernel, on the stream it is launched
-        # on, so that its per-launch duration is measured live without loading every launch with
-        # event records; the per-kernel breakdown comes from a short untimed pass.
+        # on, and only every n-th of its launches (--profile-every; n = 5 walks through the positions
+        # of an 8-haystack step), so that its per-launch duration is measured live without loading
+        # the step with event records: a bracketed launch has 8 us of stream time on either side
+        # where an unbracketed kernel boundary has 0 - 3.5 (profiles/r04/event_gaps.txt).  The
+        # per-kernel breakdown comes from a short untimed pass.
         am.set_option("profile_mask", 1 << KN.index(dom))
+        am.set_option("profile_every", max(1, args.profile_every))
         sync()
         R.barrier()
         with am.Profile(device) as prof:
@@ -645,6 +652,7 @@ def main():
         units_per_step = W.units_per_haystack() * B * R.world
     else:
         am.set_option("profile_mask", 1 << KN.index(dom))
+        am.set_option("profile_every", max(1, args.profile_every))
         strong_batch(am, R, W, args.total_haystacks, max(1, min(args.warmup, 1)), rpd)
         with am.Profile(device) as prof:
             local_dt, wave = strong_batch(am, R, W, args.total_haystacks, args.steps, rpd)
@@ -665,6 +673,7 @@ def main():
 
     # untimed: per-kernel breakdown of a few steps (every launch bracketed by events)
     am.set_option("profile_mask", -1)
+    am.set_option("profile_every", 1)
     extra_steps = 3
     with am.Profile(device) as prof:
         for _ in range(extra_steps):
@@ -724,7 +733,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args.config),
                      "bytes_per_launch": dom_bytes, "avg_launch_us": dom_avg_s * 1e6,
-                     "launches": dom_launches},
+                     "launches": dom_launches,
+                     "launch_sampling": f"HIP events around every {max(1, args.profile_every)}. launch of the kernel inside the timed region"},
         # the whole pipeline over the wall clock of the timed region, on the bytes THIS design moves through
         # HBM (K1 + K2 + K3 as in DESIGN.md section 5); the SURVEY.md 8(d) model (a two-pass forward and a
         # two-pass inverse transform per block) moves more bytes per sample, so its fraction is a model figure

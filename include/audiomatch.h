@@ -362,6 +362,9 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
 /* Process-wide option DEFAULTS.  A call reads them once on entry, so changing one never
  * affects a call that is already running.
  *   "log_n" (0 = auto), "pairs_per_group", "profile_mask": tuning / measurement knobs
+ *   "profile_every" (n >= 1, default 1): with profiling on, bracket only every n-th launch of a kernel class with
+ *       events (an event pair costs the stream about 8 us per kernel boundary; am_profile_query then reports the
+ *       bracketed launches' time and count)
  *   "batch_overlap" (0/1, default 1): in am_match_batch_device pick the peaks of haystack k
  *       on a second stream beside the transforms of haystack k+1
  *   "needle_group" (1..8, default 8): how many needles of am_match_multi_device share
