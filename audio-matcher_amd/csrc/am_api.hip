@@ -73,6 +73,7 @@ static std::atomic<long long> g_opt_needle_group{8};     // needles sharing one 
 static std::atomic<long long> g_opt_pick_priority{0};    // 1 = the pick's stream is created with the lowest priority (read at context creation)
 static std::atomic<long long> g_opt_pick_group{1};       // 1 = ... and so do the group's picks (0: four small launches per needle, for A/B)
 static std::atomic<long long> g_opt_k3_group{1};         // 1 = the K3s of a needle group run as one launch (0: one launch per needle, for A/B)
+static std::atomic<long long> g_opt_host_pick_wait{1};    // 1 = a batch's host thread waits for the pick that last read a score set before it queues the next haystack into it (0: the stream waits)
 static std::atomic<long long> g_opt_device_redo{1};      // 0 = failed certificates are redone by the host path only (experiments)
 static std::atomic<long long> g_opt_tail_block{1};       // 1 = a haystack's last, odd block goes through the next smaller plan (TailPlan); 0 = as half of a full pair
 static std::atomic<long long> g_opt_dense{0};            // 1 = K3 writes every raw score (theta = -inf): the worst case of the sparse-score path
@@ -89,7 +90,7 @@ static std::atomic<long long> g_opt_tail_window{0};         // 0 = chunked() emi
 static std::atomic<long long> g_opt_surrounding_from{0};    // filter_surrounding's neighbours: 0 = of the sorted, unfiltered sequence; 1 = the neighbour before is the last element kept
 struct Opts {
     long long log_n, pairs_per_group, half, batch_overlap, needle_group, dense, device_redo, debug_no_realloc, debug_redo_arm_at;
-    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group, pick_group, tail_block;
+    long long peak_filter_order, distance_rule, tail_window, surrounding_from, k3_group, pick_group, tail_block, host_pick_wait;
     PeakPolicy peak_policy() const { return PeakPolicy{(int)peak_filter_order, (int)(distance_rule & 1), (int)((distance_rule >> 1) & 1)}; }
 };
 static const float kHalfGain = 1024.0f;      // keeps the stored values of a normalised score near 1
@@ -510,6 +511,7 @@ static Opts snapshot_opts(const am_needle* h) {
     o.k3_group = g_opt_k3_group.load(std::memory_order_relaxed);
     o.pick_group = g_opt_pick_group.load(std::memory_order_relaxed);
     o.tail_block = g_opt_tail_block.load(std::memory_order_relaxed);
+    o.host_pick_wait = g_opt_host_pick_wait.load(std::memory_order_relaxed);
     return o;
 }
 
@@ -1574,7 +1576,14 @@ static int match_many(am_needle* h, const void* const* d_hays, const size_t* len
         float* d_scores = (float*)(set ? c->scores_b.p : c->scores.p);
         scan.set = set;
         // this set's work matrix, scores and summaries are overwritten: the pick (and redo) that last used them must be done
-        if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
+        // (On the host: this thread runs far ahead of the GPU -- it queues a haystack in 35 us, the GPU takes 700 -- so
+        // waiting here for the pick of the haystack before the previous one leaves more than a haystack's work queued,
+        // and the main stream is spared a barrier packet between K3 and the next K1: that boundary measured 6.5 us
+        // instead of 11 - 27, profiles/r04/event_gaps.txt.  Option host_pick_wait = 0: the stream waits.)
+        if (overlap && seq >= 2) {
+            if (o.host_pick_wait) AM_HIP(hipEventSynchronize(c->ev_pick[set]));
+            else AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
+        }
         scan.before_k3 = nullptr;
         scan.work_by_set = overlap;
         int* d_redo = nullptr;
@@ -3377,6 +3386,7 @@ int am_set_option(const char* key, long long value) {
     if (!strcmp(key, "profile_every")) { g_opt_profile_every = value < 1 ? 1 : value; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { g_opt_dense = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "tail_block")) { g_opt_tail_block = value ? 1 : 0; return AM_OK; }
+    if (!strcmp(key, "host_pick_wait")) { g_opt_host_pick_wait = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "device_redo")) { g_opt_device_redo = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "k3_group")) { g_opt_k3_group = value ? 1 : 0; return AM_OK; }
     if (!strcmp(key, "pick_group")) { g_opt_pick_group = value ? 1 : 0; return AM_OK; }
@@ -3412,6 +3422,7 @@ int am_get_option(const char* key, long long* value) {
     if (!strcmp(key, "profile_every")) { *value = g_opt_profile_every; return AM_OK; }
     if (!strcmp(key, "dense_scores")) { *value = g_opt_dense; return AM_OK; }
     if (!strcmp(key, "tail_block")) { *value = g_opt_tail_block; return AM_OK; }
+    if (!strcmp(key, "host_pick_wait")) { *value = g_opt_host_pick_wait; return AM_OK; }
     if (!strcmp(key, "device_redo")) { *value = g_opt_device_redo; return AM_OK; }
     if (!strcmp(key, "k3_group")) { *value = g_opt_k3_group; return AM_OK; }
     if (!strcmp(key, "pick_group")) { *value = g_opt_pick_group; return AM_OK; }

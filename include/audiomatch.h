@@ -385,6 +385,9 @@ int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t*
  *       to rounding (1e-6); a haystack's results do not depend on the batch it travels in.  Single-needle entry points
  *       (am_match*, am_pool_match_batch*, am_pool_match_long*, am_match_part_device); not the several-needle engine,
  *       not streaming ingest, not a forced "log_n".
+ *   "host_pick_wait" (0/1, default 1): in a batch, the calling thread (not the stream) waits for the peak pick that
+ *       last read a set of score buffers before it queues the next haystack into that set -- it runs far ahead of the
+ *       GPU either way, and the main stream is spared a barrier packet per haystack (results are identical).
  *   "device_redo" (0/1, default 1): in a batch, chunks whose sparse-score certificate fails get their dense
  *       inverse pass on the device, beside the next haystack's transforms; 0 = the host path does it
  *       after the call's kernels (results are identical; for measurements).
