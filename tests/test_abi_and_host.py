@@ -52,6 +52,18 @@ def test_pure_host_entry_points(amlib):
     assert b"unknown" in L.am_last_error_string()
     assert L.am_set_option(b"log_n", 0) == 0
     assert amlib.get_option("pairs_per_group") >= 1
+    # every documented option reads back what was set (and its default afterwards); values are clamped to their range
+    for key, default, other in (("tail_block", 1, 0), ("host_pick_wait", 1, 0), ("profile_every", 1, 5), ("dense_scores", 0, 1),
+                                ("device_redo", 1, 0), ("batch_overlap", 1, 0), ("k3_group", 1, 0), ("pick_group", 1, 0),
+                                ("peak_filter_order", 0, 1), ("distance_rule", 0, 3), ("tail_window", 0, 1), ("surrounding_from", 0, 1),
+                                ("debug_no_realloc", 0, 1), ("debug_redo_arm_at", -2, 3)):
+        assert amlib.get_option(key) == default, key
+        amlib.set_option(key, other)
+        assert amlib.get_option(key) == other, key
+        amlib.set_option(key, default)
+        assert amlib.get_option(key) == default, key
+    amlib.set_option("profile_every", 0)
+    assert amlib.get_option("profile_every") == 1
 
 
 def test_no_device_fails_loudly(amlib):
