@@ -379,14 +379,17 @@ static void build_mfma_tables(std::vector<unsigned>& tab) {
     }
 }
 
-static int get_plan(Ctx* c, int logN, const Plan** out) {
-    auto it = c->plans.find(logN);
+// force_logN1: another factorisation than the production one (am_debug_column_bench: 2^23 as 512 x 16384)
+static int get_plan(Ctx* c, int logN, const Plan** out, int force_logN1 = 0) {
+    const int key = force_logN1 ? 1000 * force_logN1 + logN : logN;
+    auto it = c->plans.find(key);
     if (it != c->plans.end()) { *out = &it->second; return AM_OK; }
     if (logN < kLogNMin || logN > kLogNMax) return fail(AM_ERR_INVALID_ARG, "unsupported transform size");
     Plan p;
     int logN1 = logN - 13;
     if (logN1 < kColsLog) logN1 = kColsLog;
     if (logN1 > 10) logN1 = 10;
+    if (force_logN1) logN1 = force_logN1;
     int logN2 = logN - logN1;
     // N = 2^21 -> 256 x 8192, N = 2^22 -> 512 x 8192, N = 2^23 -> 1024 x 8192: the register kernels
     const int logLo = (logN + 1) / 2;
@@ -439,7 +442,7 @@ static int get_plan(Ctx* c, int logN, const Plan** out) {
         AM_HIP(copy_on_stream(c, p.mf, tab.data(), tab.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         p.dev.mf = p.mf;
     }
-    auto ins = c->plans.emplace(logN, p);
+    auto ins = c->plans.emplace(key, p);
     *out = &ins.first->second;
     return AM_OK;
 }
@@ -3338,6 +3341,51 @@ int am_set_chunk_progress_callback(am_chunk_progress_fn fn, void* user) {
     std::lock_guard<std::mutex> lk(g_hooks_mu);
     g_hooks.chunk_fn = fn;
     g_hooks.chunk_user = user;
+    return AM_OK;
+}
+
+// Measurement hook (not part of the drop-in boundary): the column kernels K1 and K3 on `npairs` block pairs of
+// synthetic input, `iters` launches each, average launch time in ms.  wide = 0: the production 2^22 plan
+// (512 x 8192); wide = 1: 2^23 factored 512 x 16384 -- the same 512-row kernels on rows twice as long (no row kernel
+// exists for that plan yet: this sizes what it would be worth).  dense: K3 writes every run / none.
+int am_debug_column_bench(int device, int wide, int npairs, int iters, int dense, double* k1_ms, double* k3_ms) {
+    Ctx* c = nullptr;
+    int rc = get_ctx(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (npairs < 1 || npairs > 64 || iters < 1 || !k1_ms || !k3_ms) return fail(AM_ERR_INVALID_ARG, "bad arguments");
+    const Plan* pl = nullptr;
+    if ((rc = wide ? get_plan(c, 23, &pl, 9) : get_plan(c, 22, &pl))) return rc;
+    const long long N = 1ll << pl->dev.logN, s = 441000, hop = ((N - s + 1) / kTile) * kTile;
+    const long long nblocks = 2ll * npairs, out_count = nblocks * hop, src_len = out_count + s - 1 + kTile;
+    DevBuf src, work, scores, stats32, side;
+    if ((rc = src.ensure((size_t)src_len * 4)) || (rc = work.ensure((size_t)npairs * (size_t)N * sizeof(float2))) ||
+        (rc = scores.ensure((size_t)out_count * 4)) || (rc = stats32.ensure((size_t)(out_count / 32) * sizeof(float2))) ||
+        (rc = side.ensure(sparse_bytes(nblocks, pl->dev)))) return rc;
+    AM_HIP(launch_synth(c->stream, (float*)src.p, 7, 1, 0, src_len, 0.25f));
+    Job job{};
+    job.src = src.p; job.src_len = src_len; job.lead = 0; job.src_kind = 0;
+    job.dst = (float*)scores.p; job.out_count = out_count; job.hop = (int)hop; job.nblocks = (int)nblocks; job.first_pair = 0;
+    ScanCfg scan{};
+    fill_scan_cfg(&scan, stats32.p, side.p, nblocks, pl->dev, dense ? -1.0f : 1e30f, FLT_MAX, 60 * 44100, 70 * 44100 - s);
+    hipEvent_t e[3];
+    for (auto& x : e) AM_HIP(hipEventCreate(&x));
+    double t1 = 0, t3 = 0;
+    for (int it = -2; it < iters; ++it) {   // (two untimed rounds first)
+        AM_HIP(hipEventRecord(e[0], c->stream));
+        AM_HIP(launch_k1(c->stream, job, npairs, (float2*)work.p, pl->dev, 0));
+        AM_HIP(hipEventRecord(e[1], c->stream));
+        AM_HIP(launch_k3(c->stream, job, npairs, (const float2*)work.p, pl->dev, 1e-3f, scan, 0, false));
+        AM_HIP(hipEventRecord(e[2], c->stream));
+        AM_HIP(hipStreamSynchronize(c->stream));
+        float a = 0, b = 0;
+        AM_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+        AM_HIP(hipEventElapsedTime(&b, e[1], e[2]));
+        if (it >= 0) { t1 += a; t3 += b; }
+    }
+    for (auto& x : e) (void)hipEventDestroy(x);
+    src.release(); work.release(); scores.release(); stats32.release(); side.release();
+    *k1_ms = t1 / iters; *k3_ms = t3 / iters;
     return AM_OK;
 }
 

@@ -2154,11 +2154,14 @@ constexpr int kC512Slab3 = 32 * 16 + 16;
 __device__ __forceinline__ int c512_idx3(int ap, int b, int cp) { return ap * kC512Slab3 + b * 16 + cp; }
 static_assert((15 * kC512Slab3 + 31 * 16 + 16) * 8 <= kC512Lds, "K3's exchange fits the kernel's LDS");
 
-template <int KIND, int HALF>   // HALF: 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and f16 butterflies
+// LN2: log2 of the row length (13: N = 2^22 = 512 x 8192, the production plan; 14: N = 2^23 = 512 x 16384, see
+// am_debug_column_bench -- the column kernels do not care how long a row is, only the strides change)
+template <int KIND, int HALF, int LN2 = kR16LogN2>   // HALF: 0 = f32 work matrix, 1 = f16 storage, 2 = f16 storage and f16 butterflies
 // (second argument: waves per SIMD = two workgroups per CU: held to 128 VGPRs -- left alone the allocator takes
 // 130 - 150 and the kernel runs alone on its CU)
 __global__ void __launch_bounds__(512, 4)
 k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
+    constexpr int kN2 = 1 << LN2;   // (shadows the 8192 of the other plans)
     extern __shared__ float4 lds4[];
     float2* lds2 = reinterpret_cast<float2*>(lds4);
     const int t = threadIdx.x;
@@ -2303,17 +2306,19 @@ k1_cols_fwd_c512(Job job, float2* __restrict__ work, PlanDev pl) {
     }
 }
 
-template <int HALF, bool ACC>   // as in k1_cols_fwd_c512
+template <int HALF, bool ACC, int LN2 = kR16LogN2>   // as in k1_cols_fwd_c512
 __device__ __forceinline__ void k3_cols_inv_c512_tile(unsigned lin, float4* lds4, const Job& job, const float2* __restrict__ work,
                                                       const PlanDev& pl, float out_scale, const ScanCfg& scan, const ScanCfg* geo = nullptr) {
+    constexpr int kN2 = 1 << LN2;
     float2* lds2 = reinterpret_cast<float2*>(lds4);
     const int t = threadIdx.x;
     const int hi = t >> 4, cp = t & 15;
     const int ap = hi & 15, half = hi >> 4;
     const int k10 = ap + 16 * half;
     // placement as in k3_cols_inv_r16: the 16 column tiles that share a line of the summary on one XCD
+    // (256 tiles per pair = 8 XCDs x 2 x 16; with rows of 16384 points 512 = 8 x 4 x 16)
     const unsigned xcd = lin & 7u, seq = lin >> 3;
-    const unsigned slot = seq >> 5, hf = (seq >> 4) & 1u, tl = seq & 15u;
+    const unsigned slot = seq >> (LN2 - 8), hf = (seq >> 4) & ((1u << (LN2 - 12)) - 1u), tl = seq & 15u;
     const int n2_0 = (int)(((hf * 8u + xcd) * 16u + tl) << kColsLog);
     const int pair = job.first_pair + (int)slot;
     if (scan.only_pairs != nullptr && scan.only_pairs[pair] == 0) return;   // device-side redo: flagged pairs only
@@ -2512,6 +2517,13 @@ k3_cols_inv_c512(Job job, const float2* __restrict__ work, PlanDev pl, float out
     } else {
         k3_cols_inv_c512_tile<HALF, ACC>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
     }
+}
+
+// The same tile for rows of 16384 points (N = 2^23 = 512 x 16384; f32 work matrix; am_debug_column_bench)
+__global__ void __launch_bounds__(512, 2)
+k3_cols_inv_c512w(Job job, const float2* __restrict__ work, PlanDev pl, float out_scale, ScanCfg scan) {
+    extern __shared__ float4 lds4[];
+    k3_cols_inv_c512_tile<0, false, 14>(blockIdx.x, lds4, job, work, pl, out_scale, scan);
 }
 
 // The needles of a group in one launch (launch_k3_group): blockIdx.y picks the needle, everything else is the
@@ -2968,6 +2980,7 @@ static constexpr int kR16LdsK3 = 256 * 16 * 8;
 bool plan_is_r16(const PlanDev& pl) { return pl.logN1 == kR16LogN1 && pl.logN2 == kR16LogN2; }
 bool plan_is_c512(const PlanDev& pl) { return pl.logN1 == 9 && pl.logN2 == kR16LogN2; }
 bool plan_is_c1024(const PlanDev& pl) { return pl.logN1 == 10 && pl.logN2 == kR16LogN2; }
+bool plan_is_c512w(const PlanDev& pl) { return pl.logN1 == 9 && pl.logN2 == 14; }   // 512 x 16384 (column kernels only, so far)
 bool plan_has_scan(const PlanDev& pl) { return plan_is_r16(pl) || plan_is_c512(pl) || plan_is_c1024(pl); }
 // the row kernel only needs 8192-point rows; it serves any N1 (its rows are independent)
 bool plan_k2_is_r16(const PlanDev& pl) { return pl.logN2 == kR16LogN2 && pl.logN1 >= 3; }
@@ -3006,6 +3019,8 @@ hipError_t fft_kernels_init() {
     AM_SET_LDS((k3_cols_inv_r16<2, false, 1>), kR16LdsK3)
     AM_SET_LDS(k3_cols_inv_c1024<true>, kC1024Lds)
     AM_SET_LDS(k3_cols_inv_c512_group, kC512Lds)
+    AM_SET_LDS(k3_cols_inv_c512w, kC512Lds)
+    AM_SET_LDS((k1_cols_fwd_c512<0, 0, 14>), kC512Lds)
     AM_SET_LDS(k3_cols_inv_r16_group, kR16LdsK3)
     AM_SET_LDS(tail_cols_inv_r16<0>, kR16LdsK3)
     AM_SET_LDS(tail_cols_inv_r16<1>, kR16LdsK3)
@@ -3038,7 +3053,10 @@ hipError_t fft_kernels_init() {
 hipError_t launch_k1(hipStream_t st, const Job& job, int npairs, float2* work, const PlanDev& pl, int half) {
     const dim3 grid((1u << pl.logN2) >> kColsLog, npairs);
     const bool pcm = job.src_kind == 1;
-    if (plan_is_c1024(pl)) {
+    if (plan_is_c512w(pl)) {
+        if (half || pcm) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k1_cols_fwd_c512<0, 0, 14>), grid, dim3(512), kC512Lds, st, job, work, pl);
+    } else if (plan_is_c1024(pl)) {
         if (half) return hipErrorInvalidValue;   // (f32 work matrix only)
         if (pcm) hipLaunchKernelGGL(k1_cols_fwd_c1024<1>, grid, dim3(1024), kC1024Lds, st, job, work, pl);
         else hipLaunchKernelGGL(k1_cols_fwd_c1024<0>, grid, dim3(1024), kC1024Lds, st, job, work, pl);
@@ -3223,6 +3241,11 @@ hipError_t launch_k3(hipStream_t st, const Job& job, int npairs, const float2* w
             else if (half) hipLaunchKernelGGL((k3_cols_inv_r16<1, false, 1>), g1, dim3(256), kR16LdsK3, st, job, work, pl, out_scale, scan);
             else hipLaunchKernelGGL((k3_cols_inv_r16<0, false, 1>), g1, dim3(256), kR16LdsK3, st, job, work, pl, out_scale, scan);
         }
+        return hipGetLastError();
+    }
+    if (plan_is_c512w(pl)) {
+        if (half || accumulate || scan.only_pairs != nullptr) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k3_cols_inv_c512w, dim3((unsigned)npairs * ((1u << pl.logN2) >> kColsLog)), dim3(512), kC512Lds, st, job, work, pl, out_scale, scan);
         return hipGetLastError();
     }
     if (accumulate && half) return hipErrorInvalidValue;   // (the accumulating forms exist for the f32 work matrix only)

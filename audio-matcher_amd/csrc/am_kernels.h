@@ -152,6 +152,7 @@ constexpr int kDirectMaxNeedle = 64;
 hipError_t launch_direct(hipStream_t st, const Job& job, const float* needle, int s, float out_scale);
 bool plan_is_r16(const PlanDev& pl);
 bool plan_is_c512(const PlanDev& pl);    // N = 2^22 = 512 x 8192, 512-thread column kernels
+bool plan_is_c512w(const PlanDev& pl);   // N = 2^23 = 512 x 16384: the 512-row column kernels on longer rows (measurement only: no row kernel yet)
 bool plan_is_c1024(const PlanDev& pl);   // N = 2^23 = 1024 x 8192, 1024-thread column kernels (f32 work matrix only)
 bool plan_has_scan(const PlanDev& pl);   // K3 of this plan carries the fused score scan
 bool plan_k2_is_r16(const PlanDev& pl);

@@ -359,6 +359,12 @@ int am_profile_enable(int device, int on);
 int am_profile_reset(int device);
 int am_profile_query(int device, const char* kernel, double* total_ms, uint64_t* launches);
 
+/* Measurement hook, not part of the drop-in boundary: the two column kernels on `npairs` block pairs of synthetic
+ * input, `iters` launches each, average launch time in ms.  wide = 0: the production 2^22-point plan (512 x 8192);
+ * wide = 1: 2^23 points factored 512 x 16384, i.e. the same 512-row kernels on rows twice as long (no row kernel exists
+ * for that factorisation yet; DESIGN.md 9.3 sizes it with this).  dense != 0: the inverse kernel writes every score. */
+int am_debug_column_bench(int device, int wide, int npairs, int iters, int dense, double* k1_ms, double* k3_ms);
+
 /* Process-wide option DEFAULTS.  A call reads them once on entry, so changing one never
  * affects a call that is already running.
  *   "log_n" (0 = auto), "pairs_per_group", "profile_mask": tuning / measurement knobs
