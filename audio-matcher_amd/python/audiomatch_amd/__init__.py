@@ -166,6 +166,7 @@ _SIGNATURES = {
     "am_match_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "am_match_stream_finish": (C.c_int, [C.c_void_p, C.POINTER(AmPeak), C.c_size_t, C.POINTER(C.c_size_t)]),
     "am_match_stream_destroy": (None, [C.c_void_p]),
+    "am_debug_column_bench": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "am_profile_enable": (C.c_int, [C.c_int, C.c_int]),
     "am_profile_reset": (C.c_int, [C.c_int]),
     "am_profile_query": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

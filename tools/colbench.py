@@ -8,8 +8,6 @@ sys.path.insert(0, "audio-matcher_amd/python"); sys.path.insert(0, "audio-matche
 import audiomatch_amd as am
 
 L = am.lib()
-L.am_debug_column_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-L.am_debug_column_bench.restype = C.c_int
 for rnd in range(2):
     for dense in (0, 1):
         for wide, pairs in ((0, 20), (1, 10), (0, 22), (1, 11)):
