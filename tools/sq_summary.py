@@ -20,11 +20,17 @@ def main():
             vals[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
     res = {}
     for key, pat in KEYS.items():
-        agg = {}
+        agg, agg_grid = {}, -1
         for name, counters in vals.items():
             pats = (pat,) if isinstance(pat, str) else pat
             if not any(p_ in name for p_ in pats) or name.split("(")[0].rstrip().endswith(", 1>"):   # (skip the device-side redo's K3 instantiations)
                 continue
+            # several kernels can match a class (the 256-row forms build the tail plan's needle spectrum): the one
+            # with the largest grid is the pipeline's
+            grid = max(g for lst in counters.values() for _, g in lst)
+            if grid <= agg_grid:
+                continue
+            agg, agg_grid = {}, grid
             for cname, lst in counters.items():
                 gmax = max(g for _, g in lst)
                 full = sorted(v for v, g in lst if g == gmax)
