@@ -640,3 +640,51 @@ def test_odd_last_block_redo_nan_and_half_paths(gpu, oracle):
     finally:
         gpu.set_option("tail_block", 1)
         ha.close()
+
+
+def test_odd_last_block_with_my_scaling_and_window_policy(gpu, oracle):
+    """The tail block under the two rules that treat the END of a haystack specially: MyConvolve's scaling (the
+    shorter windows at the end get their own factor and a pass of their own, audio_matcher.rs:442-448) and the
+    policy switch tail_window = 1 (full-length windows only).  Haystack of 2 blocks of the 2^22 plan and a part-filled
+    third, hits in the main pass, in the tail block's stretch and in the last, shorter window; offsets == checker,
+    heights relative 1e-4, alone and in a batch, with the option on and off."""
+    sr = 44100
+    s = 10 * sr
+    hop, hop_t = tail_geometry(s)
+    T = 2 * hop
+    chunk, overlap = 60 * sr, 10 * sr
+    window = chunk + overlap
+    needle, hay, offs, _ = tail_case(oracle, sr, s, 1900000, 221, lambda T, ht, out: [25 * sr, T + 2 * sr, out - 1 - 4 * sr])
+    n_windows = -(-hay.size // chunk)
+    assert (n_windows - 1) * chunk + window > hay.size and offs[2] > (n_windows - 1) * chunk    # the last window is a short one and holds a hit
+    prom = 0.3 / window
+    pm = gpu.AmMatchParams(sr=sr, chunk=chunk, overlap=overlap, min_prominence=prom, min_distance=2 * sr,
+                           overshadow_distance_s=2.0, scale=int(gpu.Scale.MY))
+    exp_my = oracle.calc_chunks(sr, hay, needle, chunk, overlap, prom, 2 * sr, 2.0, scale=oracle.SCALE_MY)
+    assert [e[0] for e in exp_my] == offs
+    pl = gpu.AmMatchParams(sr=sr, chunk=chunk, overlap=overlap, min_prominence=0.3, min_distance=2 * sr,
+                           overshadow_distance_s=2.0, scale=int(gpu.Scale.LIB))
+    exp_full = oracle.calc_chunks(sr, hay, needle, chunk, overlap, 0.3, 2 * sr, 2.0, pol=oracle.policy(tail_window=1))
+    assert [e[0] for e in exp_full] == offs[:2]                     # the short last window is not emitted: its hit is gone
+    algo = gpu.HipConvolve(needle)
+    buf = gpu.DeviceBuffer.from_numpy(0, hay)
+    rel = lambda got, exp: all(abs(g.height - e[2]) < 1e-4 * abs(e[2]) and abs(g.prominence - e[3]) < 1e-4 * abs(e[3]) for g, e in zip(got, exp))
+    try:
+        for on in (1, 0):
+            gpu.set_option("tail_block", on)
+            one = algo.match_device(buf.ptr, hay.size, pm)
+            assert [(g.start, g.end) for g in one] == [(e[0], e[1]) for e in exp_my] and rel(one, exp_my), on
+            both = algo.match_batch_device([buf.ptr, buf.ptr, buf.ptr], [hay.size] * 3, pm)
+            assert all(key(b) == key(one) for b in both), on
+            gpu.set_option("tail_window", 1)
+            try:
+                one = algo.match_device(buf.ptr, hay.size, pl)
+                assert [(g.start, g.end) for g in one] == [(e[0], e[1]) for e in exp_full] and rel(one, exp_full), on
+                both = algo.match_batch_device([buf.ptr, buf.ptr], [hay.size] * 2, pl)
+                assert all(key(b) == key(one) for b in both), on
+            finally:
+                gpu.set_option("tail_window", 0)
+    finally:
+        gpu.set_option("tail_block", 1)
+        gpu.set_option("tail_window", 0)
+        algo.close()
