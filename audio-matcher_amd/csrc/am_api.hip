@@ -223,10 +223,10 @@ struct Ctx {
 
 // Events that order the library's streams of ONE device among themselves (the pick behind K3, K3 behind the pick that
 // last read its score set, the tail stream) and the events that time kernels: without the system-scope fence a default
-// event performs when it is recorded -- a write-back and invalidation of the caches that the next kernel then pays
-// for (a kernel boundary with such an event in it measured 8 us, one without 1.8 us: profiles/r04/event_fence_ab.txt).
-// Kernel boundaries order device memory by themselves; what the host reads (result headers in pinned memory) it reads
-// behind a hipStreamSynchronize.
+// event performs when it is recorded (a write-back and invalidation of the caches).  Nothing here needs that fence:
+// kernel boundaries order device memory by themselves, and what the host reads (result headers in pinned memory) it
+// reads behind a hipStreamSynchronize.  Measured -0.7 % on the headline, near the noise: what an event costs a stream
+// is its barrier packet, 4 - 8 us of a kernel boundary, fence or not (profiles/r04/event_gaps.txt).
 #ifndef AM_EVENT_NO_SYSTEM_FENCE
 #define AM_EVENT_NO_SYSTEM_FENCE 1
 #endif
@@ -3359,6 +3359,7 @@ int am_debug_column_bench(int device, int wide, int npairs, int iters, int dense
     const long long N = 1ll << pl->dev.logN, s = 441000, hop = ((N - s + 1) / kTile) * kTile;
     const long long nblocks = 2ll * npairs, out_count = nblocks * hop, src_len = out_count + s - 1 + kTile;
     DevBuf src, work, scores, stats32, side;
+    struct Release { DevBuf* b[5]; ~Release() { for (DevBuf* x : b) x->release(); } } release_all{{&src, &work, &scores, &stats32, &side}};
     if ((rc = src.ensure((size_t)src_len * 4)) || (rc = work.ensure((size_t)npairs * (size_t)N * sizeof(float2))) ||
         (rc = scores.ensure((size_t)out_count * 4)) || (rc = stats32.ensure((size_t)(out_count / 32) * sizeof(float2))) ||
         (rc = side.ensure(sparse_bytes(nblocks, pl->dev)))) return rc;
@@ -3384,7 +3385,6 @@ int am_debug_column_bench(int device, int wide, int npairs, int iters, int dense
         if (it >= 0) { t1 += a; t3 += b; }
     }
     for (auto& x : e) (void)hipEventDestroy(x);
-    src.release(); work.release(); scores.release(); stats32.release(); side.release();
     *k1_ms = t1 / iters; *k3_ms = t3 / iters;
     return AM_OK;
 }
