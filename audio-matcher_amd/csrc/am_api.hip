@@ -186,6 +186,7 @@ struct Ctx {
     hipStream_t stream_tail = nullptr;       // a haystack's odd last block on the smaller plan, beside its main pass (run_tail_block)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf work_tail, tail_scores, tail_stats;   // (a batch computes the tails of up to kMaxTailBatch haystacks per launch: two alternating halves)
+    DevBuf work_tail2;                           // several needles: the tail's inverse rows, one matrix per needle of a group
     std::recursive_mutex mu;
     std::map<int, Plan> plans;
     DevBuf work, work2, scores, stats, stats32, wflags, segs, peaks, io_in, io_out, sum, arena_cur, wide_ctl, wide_list, wide_tiles;
@@ -1861,7 +1862,8 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
     std::vector<Segment> segs;
     std::vector<int> seg_off(n_hay + 1, 0);
     std::vector<Geometry> geo(n_hay);
-    size_t max_scores = 0, max_segs = 1, max_work = 0, max_matrix = 0, max_wflags = 0;
+    std::vector<TailPlan> tails(n_hay);   // the odd last block on the 2^21 plan (TailPlan), for haystacks whose needle groups all take the grouped K3
+    size_t max_scores = 0, max_segs = 1, max_work = 0, max_matrix = 0, max_wflags = 0, max_tail = 0;
     int rc;
     for (size_t k = 0; k < n_hay; ++k) {
         seg_off[k] = (int)segs.size();
@@ -1877,6 +1879,7 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         max_work = std::max(max_work, matrix);
         max_matrix = std::max(max_matrix, matrix);
         { const Plan* plk = nullptr; if ((rc = get_plan(c, geo[k].logN, &plk))) return rc; max_wflags = std::max(max_wflags, sparse_bytes(geo[k].nblocks, plk->dev)); }
+        tail_plan(s, out_count, o, geo[k], &tails[k]);
     }
     seg_off[n_hay] = (int)segs.size();
     const size_t nsegs = segs.size();
@@ -1898,6 +1901,32 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         }
     }
     const size_t group_opt = (size_t)std::min<long long>(std::max<long long>(1, o.needle_group), kMaxNeedleGroup);
+    // The tail needs every needle group of the haystack on the grouped-K3 path (the other paths keep the full layout):
+    // f32, groups of at least two needles each, the 512-row plan with a 256-row tail.
+    {
+        const bool groups_ok = o.k3_group && group_opt > 1 && nn > 1 && !o.half && (nn % group_opt) != 1 && c->stream_tail != nullptr;
+        for (size_t k = 0; k < n_hay; ++k) {
+            if (!tails[k].on) continue;
+            const Plan* plk = nullptr;
+            if (seg_off[k + 1] == seg_off[k] || !groups_ok || !tail_batchable(tails[k]) || get_plan(c, geo[k].logN, &plk) || !plan_is_c512(plk->dev)) {
+                tails[k].on = false;
+                continue;
+            }
+            max_tail = std::max(max_tail, (size_t)tails[k].g.N);
+            if (!hcs.count(tails[k].g.logN)) {   // the needles' spectra on the tail's plan
+                const Plan* plt = nullptr;
+                if ((rc = get_plan(c, tails[k].g.logN, &plt))) return rc;
+                std::vector<const float2*>& v = hcs[tails[k].g.logN];
+                v.resize(nn);
+                for (size_t j = 0; j < nn; ++j)
+                    if ((rc = needle_spectrum(needles[j], plt, &v[j]))) return rc;
+            }
+        }
+        if (max_tail) {
+            if ((rc = c->work_tail.ensure(std::max(c->work_tail.cap, max_tail * sizeof(float2))))) return rc;
+            if ((rc = c->work_tail2.ensure(std::min(group_opt, nn) * max_tail * sizeof(float2)))) return rc;
+        }
+    }
     size_t n_pairs_active = 0;
     for (size_t k = 0; k < n_hay; ++k) n_pairs_active += seg_off[k + 1] > seg_off[k] ? nn : 0;
     const bool overlap = o.batch_overlap && n_pairs_active > 1 && c->stream2 &&
@@ -1955,10 +1984,25 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
         const size_t group = (!half && plan_k2_has_group(pl->dev)) ? group_opt : 1;
         const size_t matrix = (size_t)g.npairs * (size_t)g.N;
         const bool fused = plan_has_scan(pl->dev) && (g.hop % kTile) == 0;
-        Job job{};
+        // The odd last block (TailPlan): the main pass -- K1 here, every group's K2 and K3 below -- stops at the even
+        // block boundary, the scores behind it come from one pair of the 2^21 plan: K1 once, then per needle group one
+        // row-kernel launch and one K3 launch (every run written) behind the group's own, and the main layout's
+        // ballots / thresholds of that block preset for the group's needles.
+        const TailPlan& tail = tails[k];
+        const int main_pairs = (int)(tail.on ? g.npairs - 1 : g.npairs);
+        const Plan* plt = nullptr;
+        Job job{}, job_t{};
         job.src = d_hays[k]; job.src_len = (long long)lens[k]; job.lead = 0; job.src_kind = src_kind;
-        job.out_count = out_count; job.hop = (int)g.hop; job.nblocks = (int)g.nblocks; job.first_pair = 0;
-        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, (int)g.npairs, (float2*)c->work.p, pl->dev, half)); }
+        job.out_count = tail.on ? tail.T : out_count; job.hop = (int)g.hop; job.nblocks = (int)(tail.on ? g.nblocks - 1 : g.nblocks); job.first_pair = 0;
+        { ProfScope ps(c, KN_K1); AM_HIP(launch_k1(c->stream, job, main_pairs, (float2*)c->work.p, pl->dev, half)); }
+        if (tail.on) {
+            if ((rc = get_plan(c, tail.g.logN, &plt))) return rc;
+            job_t.src = static_cast<const char*>(d_hays[k]) + 4 * (size_t)tail.T; job_t.src_len = (long long)lens[k] - tail.T; job_t.lead = 0;
+            job_t.src_kind = src_kind; job_t.out_count = out_count - tail.T; job_t.hop = (int)tail.g.hop; job_t.nblocks = (int)tail.g.nblocks;
+            job_t.first_pair = 0;
+            ProfScope ps(c, KN_OTHER);
+            AM_HIP(launch_k1(c->stream, job_t, 1, (float2*)c->work_tail.p, plt->dev, 0));
+        }
         for (size_t j = 0; j < nn; ++j) {
             am_needle* h = needles[j];
             const size_t in_group = j % group;
@@ -1968,8 +2012,15 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
                 K2Group grp{};
                 grp.n = (int)gn;
                 for (int q = 0; q < grp.n; ++q) { grp.hc[q] = hc[j + q]; grp.dst[q] = (float2*)c->work2.p + (size_t)q * matrix; }
-                ProfScope ps(c, KN_K2);
-                AM_HIP(launch_k2_group(c->stream, (int)g.npairs, (const float2*)c->work.p, grp, pl->dev));
+                { ProfScope ps(c, KN_K2); AM_HIP(launch_k2_group(c->stream, main_pairs, (const float2*)c->work.p, grp, pl->dev)); }
+                if (tail.on) {
+                    K2Group gt{};
+                    gt.n = (int)gn;
+                    const std::vector<const float2*>& hct = hcs[tail.g.logN];
+                    for (int q = 0; q < gt.n; ++q) { gt.hc[q] = hct[j + q]; gt.dst[q] = (float2*)c->work_tail2.p + (size_t)q * (size_t)tail.g.N; }
+                    ProfScope ps(c, KN_OTHER);
+                    AM_HIP(launch_k2_group(c->stream, 1, (const float2*)c->work_tail.p, gt, plt->dev));
+                }
             }
             // The K3s of the group as one launch (needle index on blockIdx.y), the group's picks queued behind it.
             const bool grouped_k3 = k3_group && group > 1 && gn > 1 && fused && !half && plan_k3_has_group(pl->dev);
@@ -2003,7 +2054,21 @@ static int match_multi_many(am_needle* const* needles, size_t nn, const void* co
                 }
                 // K3 overwrites this set's scores and summaries: the picks that last read them must be done
                 if (overlap && seq >= 2) AM_HIP(hipStreamWaitEvent(c->stream, c->ev_pick[set], 0));
-                { ProfScope ps(c, KN_K3); AM_HIP(launch_k3_group(c->stream, job, (int)g.npairs, kg, pl->dev, common)); }
+                { ProfScope ps(c, KN_K3); AM_HIP(launch_k3_group(c->stream, job, main_pairs, kg, pl->dev, common)); }
+                if (tail.on) {
+                    K3Group kt = kg;
+                    for (size_t q = 0; q < gn; ++q) {
+                        kt.work[q] = (const float2*)c->work_tail2.p + q * (size_t)tail.g.N;
+                        kt.dst[q] = kg.dst[q] + tail.T; kt.stats32[q] = kg.stats32[q] + tail.T / 32;
+                        kt.wbits[q] = nullptr; kt.tile_theta[q] = nullptr; kt.hist_min[q] = FLT_MAX;
+                    }
+                    ScanCfg dense{};
+                    dense.stats32 = kt.stats32[0]; dense.margin = -1.0f; dense.hist_min = FLT_MAX;
+                    ProfScope ps(c, KN_OTHER);
+                    AM_HIP(launch_k3_group(c->stream, job_t, 1, kt, plt->dev, dense));
+                    if (margin >= 0.0f)
+                        AM_HIP(launch_tail_preset_group(c->stream, kg, (long long)(g.nblocks - 1), pl->dev.logN1, pl->dev.logN2));
+                }
                 if (overlap) {
                     AM_HIP(hipEventRecord(c->ev_k3[set], c->stream));
                     AM_HIP(hipStreamWaitEvent(c->stream2, c->ev_k3[set], 0));
@@ -2893,7 +2958,7 @@ int am_shutdown(void) {
         if (c->badflag.p) { (void)hipHostFree(c->badflag.p); c->badflag.p = nullptr; c->badflag.cap = 0; }
         if (c->failcnt.p) { (void)hipHostFree(c->failcnt.p); c->failcnt.p = nullptr; c->failcnt.cap = 0; }
         c->ranges.release(); c->range_flags.release(); c->big.release();
-        c->work_tail.release(); c->tail_scores.release(); c->tail_stats.release();
+        c->work_tail.release(); c->tail_scores.release(); c->tail_stats.release(); c->work_tail2.release();
         for (int i = 0; i < 2 * kMaxNeedleGroup; ++i) { c->grp_scores[i].release(); c->grp_stats32[i].release(); c->grp_wflags[i].release(); }
         for (int i = 0; i < kMaxNeedleGroup; ++i) c->grp_stats[i].release();
         c->segs_resident.clear();

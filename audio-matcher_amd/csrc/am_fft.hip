@@ -2130,6 +2130,17 @@ tail_commit_kernel(const float* __restrict__ tsc, float* __restrict__ sc, long l
         for (long long i = tid; i < tiles; i += nth) theta[i] = -FLT_MAX;
 }
 
+__global__ void __launch_bounds__(256)
+tail_preset_group_kernel(K3Group grp, long long blk, int log_n1, int log_n2) {
+    const unsigned z = blockIdx.y;
+    const long long tiles = 1ll << (log_n2 - kColsLog), words = tiles << (log_n1 - 6);
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+    unsigned long long* __restrict__ wb = grp.wbits[z] + blk * words;
+    float* __restrict__ th = grp.tile_theta[z] + blk * tiles;
+    for (long long i = tid; i < words; i += nth) wb[i] = ~0ull;
+    for (long long i = tid; i < tiles; i += nth) th[i] = -FLT_MAX;
+}
+
 // ===========================================================================
 // N = 2^22 = 512 x 8192: column kernels with 512 threads (two waves
 // per SIMD; two workgroups = 16 waves per CU, like the 256-thread kernels at four) that hold 16
@@ -3198,6 +3209,12 @@ hipError_t launch_tail_batch_k3(hipStream_t st, const TailBatch& tb, int hop, co
     if (half == 2) hipLaunchKernelGGL(tail_cols_inv_r16<2>, grid, dim3(256), kR16LdsK3, st, tb, hop, work, pl, out_scale);
     else if (half) hipLaunchKernelGGL(tail_cols_inv_r16<1>, grid, dim3(256), kR16LdsK3, st, tb, hop, work, pl, out_scale);
     else hipLaunchKernelGGL(tail_cols_inv_r16<0>, grid, dim3(256), kR16LdsK3, st, tb, hop, work, pl, out_scale);
+    return hipGetLastError();
+}
+hipError_t launch_tail_preset_group(hipStream_t st, const K3Group& grp, long long blk, int log_n1, int log_n2) {
+    if (grp.n < 1 || grp.n > kMaxNeedleGroup) return hipErrorInvalidValue;
+    for (int z = 0; z < grp.n; ++z) if (!grp.wbits[z] || !grp.tile_theta[z]) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tail_preset_group_kernel, dim3(8, (unsigned)grp.n), dim3(256), 0, st, grp, blk, log_n1, log_n2);
     return hipGetLastError();
 }
 hipError_t launch_tail_commit(hipStream_t st, const float* tail_scores, float* scores, long long n, const float2* tail_stats32, float2* stats32,

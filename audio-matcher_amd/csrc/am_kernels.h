@@ -144,6 +144,9 @@ hipError_t launch_tail_batch_k1(hipStream_t st, const TailBatch& tb, int hop, in
 hipError_t launch_tail_batch_k3(hipStream_t st, const TailBatch& tb, int hop, const float2* work, const PlanDev& pl, float out_scale, int half);
 // A tail's scores and summary into the score-side buffers the pick reads, and the main layout's ballots / thresholds of
 // the block they belong to set to "every run written" (one small launch on the pick's stream)
+// several needles (K3Group): the ballots and thresholds of block `blk` of the main layout set to "every run written"
+// for every needle of the group, one launch
+hipError_t launch_tail_preset_group(hipStream_t st, const K3Group& grp, long long blk, int log_n1, int log_n2);
 hipError_t launch_tail_commit(hipStream_t st, const float* tail_scores, float* scores, long long n, const float2* tail_stats32, float2* stats32,
                               unsigned long long* wbits, long long words, float* theta, int tiles);
 hipError_t launch_k3_group(hipStream_t st, const Job& job, int npairs, const K3Group& grp, const PlanDev& pl, const ScanCfg& scan);

@@ -389,8 +389,9 @@ int am_debug_column_bench(int device, int wide, int npairs, int iters, int dense
  *       block boundary fit one pair of the next smaller transform (half the points), they come from that: beside the
  *       main pass for a single haystack, several haystacks per launch in a batch.  Offsets are unaffected, scores agree
  *       to rounding (1e-6); a haystack's results do not depend on the batch it travels in.  Single-needle entry points
- *       (am_match*, am_pool_match_batch*, am_pool_match_long*, am_match_part_device); not the several-needle engine,
- *       not streaming ingest, not a forced "log_n".
+ *       (am_match*, am_pool_match_batch*, am_pool_match_long*, am_match_part_device) and the several-needle engine when
+ *       every needle group holds at least two needles (the tail's forward pass once per haystack, its row and inverse
+ *       passes once per group); not streaming ingest, not a forced "log_n".
  *   "host_pick_wait" (0/1, default 1): in a batch, the calling thread (not the stream) waits for the peak pick that
  *       last read a set of score buffers before it queues the next haystack into that set -- it runs far ahead of the
  *       GPU either way, and the main stream is spared a barrier packet per haystack (results are identical).

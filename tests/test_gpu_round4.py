@@ -688,3 +688,63 @@ def test_odd_last_block_with_my_scaling_and_window_policy(gpu, oracle):
         gpu.set_option("tail_block", 1)
         gpu.set_option("tail_window", 0)
         algo.close()
+
+
+def test_odd_last_block_with_several_needles(gpu, oracle):
+    """The several-needle engine with the tail block: K1 of the tail once per haystack, its row kernel and K3 once per
+    needle group behind the group's own launches, the block's ballots and thresholds preset for the group's needles.
+    Three and nine needles of 10 s (groups of 8: nine = a group of eight and one single needle, for which the engine
+    keeps the plain layout) against two haystacks with an odd last block and one without; every needle planted in the
+    main pass, right in front of the boundary T and inside the tail; offsets == the checker == single calls, heights
+    within 1e-4 -- with the option on and off, and with a NaN that only the tail's transform reads."""
+    sr = 44100
+    s = 10 * sr
+    hop, hop_t = tail_geometry(s)
+    T = 2 * hop
+    p = gpu.Config(chunk_size_s=60.0, overlap_length_s=10.0, distance_s=2.0, prominence=0.3).params(sr, gpu.Scale.LIB)
+    nn = 9
+    needles = [oracle.synth_uniform(231, 10 + j, 0, s) for j in range(nn)]
+    out = T + 1900000
+    hays, plants = [], []
+    for k, n in enumerate((out + s - 1, out + s - 1, 4 * hop - 5000 + s - 1)):        # two with a tail, one with four full blocks
+        h = oracle.synth_uniform(231, 1 + k, 0, n)
+        pk = []
+        for j in range(nn):
+            offs = sorted({(5 + 13 * j) * sr + 3 * k, T - 5 - (3 * j + 1) * 3 * sr if j % 2 else T + 7 + 3 * j * sr, T + hop_t - 2 + (j - 4) * 3 * sr})
+            offs = [o for o in offs if o + s <= n]
+            for o in offs:
+                h[o:o + s] += needles[j]
+            pk.append(offs)
+        hays.append(h); plants.append(pk)
+    algos = [gpu.HipConvolve(n_) for n_ in needles]
+    bufs = [gpu.DeviceBuffer.from_numpy(0, h) for h in hays]
+    exps = [[oracle.calc_chunks(sr, hays[0], n_, p.chunk, p.overlap, 0.3, p.min_distance, 2.0) for n_ in needles]]   # (the checker on the first haystack; the others through the single calls)
+    assert [[e[0] for e in ex] for ex in exps[0]] == plants[0]
+    try:
+        for on in (1, 0):
+            gpu.set_option("tail_block", on)
+            singles = [[a.match_device(b.ptr, h.size, p) for a in algos] for b, h in zip(bufs, hays)]
+            for count in (3, nn):
+                res = gpu.match_multi_batch_device(algos[:count], [b.ptr for b in bufs], [h.size for h in hays], p)
+                for k in range(3):
+                    for j in range(count):
+                        assert_close_peaks(res[k][j], singles[k][j])
+                        if k == 0:
+                            assert_same(res[k][j], exps[k][j])
+                        else:
+                            assert [q.start for q in res[k][j]] == plants[k][j]
+            one = gpu.match_multi_device(algos[:3], bufs[0].ptr, hays[0].size, p)
+            for j in range(3):
+                assert_same(one[j], exps[0][j])
+        # a NaN behind everything the main pass reads: the pair goes through the single-needle path, window by window
+        gpu.set_option("tail_block", 1)
+        bad = hays[0].copy()
+        bad[bad.size - 1000] = np.nan
+        bb = gpu.DeviceBuffer.from_numpy(0, bad)
+        res = gpu.match_multi_device(algos[:3], bb.ptr, bad.size, p)
+        for j in range(3):
+            assert_same(res[j], oracle.calc_chunks(sr, bad, needles[j], p.chunk, p.overlap, 0.3, p.min_distance, 2.0))
+    finally:
+        gpu.set_option("tail_block", 1)
+        for a in algos:
+            a.close()
