@@ -39,13 +39,18 @@ def main():
            "kernels": {}}
     for key, pat in KEYS.items():
         def pick(vals):
-            best = []
+            best, best_grid = [], -1
             for name, lst in vals.items():
                 if name.split("(")[0].rstrip().endswith(", 1>"):
                     continue   # (the device-side redo's all-but-empty K3 launches run under instantiations of their own)
                 if any(p_ in name for p_ in ((pat,) if isinstance(pat, str) else pat)):
                     gmax = max(g for _, g in lst)          # full-size launches only (skip the 1-pair needle launch)
-                    best += [v for v, g in lst if g == gmax]
+                    # several kernels can match a class (the 256-row forms serve the tail block and its needle
+                    # spectrum): the pipeline's is the one with the largest grid
+                    if gmax > best_grid:
+                        best, best_grid = [], gmax
+                    if gmax == best_grid:
+                        best += [v for v, g in lst if g == gmax]
             # median over the full-size launches: the first call with a needle writes every raw
             # score (no threshold history yet) and would skew a mean
             best.sort()
